@@ -1,0 +1,151 @@
+/*
+ * libdeflate_hip.h -- C ABI of libdeflate_hip.so, the MI355X (gfx950) engine behind
+ * LibDeflate's compress / decompress hot path.
+ *
+ * Each entry point names the reference interface it replaces (LD = LibDeflate.lua,
+ * upstream v1.0.2-release).  The reference has no FFI seam of its own; the seam is cut
+ * at the *Internal functions that its public methods call after argument validation
+ * (argument validation and error strings stay in the host-language shim, see
+ * INTEGRATION.md).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Return value of every int function: 0 = ok, negative = API failure (LDH_E_*; text in
+ * ldh_last_error()).  Per-stream *data* results (LibDeflate's inflate status codes,
+ * SURVEY Q11) are written to status[] and never make the call itself fail.
+ *
+ * Threading: the library keeps one HIP stream and one workspace per process; calls are
+ * serialised by an internal mutex.  Host-pointer entry points synchronise before they
+ * return.  *_dev entry points only enqueue work on the library stream (ldh_stream());
+ * call ldh_sync() before reading results on the host.
+ */
+#ifndef LIBDEFLATE_HIP_H
+#define LIBDEFLATE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDH_FMT_DEFLATE 0 /* CompressDeflate / DecompressDeflate */
+#define LDH_FMT_ZLIB 1    /* CompressZlib / DecompressZlib */
+
+/* configs.strategy (LD:704-705) */
+#define LDH_STRATEGY_DEFAULT 0
+#define LDH_STRATEGY_FIXED 1
+#define LDH_STRATEGY_HUFFMAN_ONLY 2
+#define LDH_STRATEGY_DYNAMIC 3
+
+#define LDH_LEVEL_DEFAULT (-1) /* by input size, LD:1782-1790 */
+
+#define LDH_E_NOT_INIT (-100)
+#define LDH_E_ARG (-101)
+#define LDH_E_HIP (-102)
+#define LDH_E_NOMEM (-103)
+#define LDH_E_CAPACITY (-104) /* caller's output slot too small */
+
+/* Extra per-stream status beyond LibDeflate's codes: output slot too small (puff's 1). */
+#define LDH_STATUS_OUTPUT_FULL 1
+
+typedef struct ldh_dict ldh_dict;
+
+/* ---- lifecycle ------------------------------------------------------------- */
+int ldh_init(int device); /* selects the HIP device; idempotent for the same device */
+void ldh_shutdown(void);
+int ldh_device_count(void);
+const char *ldh_last_error(void);
+void *ldh_stream(void); /* hipStream_t the *_dev calls enqueue on */
+int ldh_sync(void);
+
+/* Largest output CompressDeflate/CompressZlib can produce for n input bytes at any
+ * level/strategy; also the required out_stride granularity (multiple of 16). */
+size_t ldh_compress_bound(size_t n);
+
+/* ---- preset dictionary: LibDeflate:CreateDictionary (LD:493-596) -------------
+ * The shim keeps the Lua-visible table {adler32,strlen,string_table,hash_tables};
+ * this handle is the device-side copy of the same bytes (1..32768 of them). */
+ldh_dict *ldh_dict_create(const uint8_t *bytes, size_t n);
+void ldh_dict_free(ldh_dict *d);
+uint32_t ldh_dict_adler32(const ldh_dict *d);
+size_t ldh_dict_len(const ldh_dict *d);
+
+/* ---- single-string forms (host pointers) -------------------------------------
+ * Replaces CompressDeflateInternal (LD:1960-1966) / CompressZlibInternal
+ * (LD:1970-2024): returns the stream and padding_bitlen. */
+int ldh_compress(const uint8_t *in, size_t n, int fmt, int level, int strategy,
+                 const ldh_dict *dict, uint8_t *out, size_t cap, size_t *out_len,
+                 int *pad_bits);
+/* Replaces DecompressDeflateInternal (LD:2648-2656) / DecompressZlibInternal
+ * (LD:2660-2727).  *status 0: out_len bytes written, *bytes_left = unprocessed input
+ * bytes; otherwise the LibDeflate status (2, -1..-17) or LDH_STATUS_OUTPUT_FULL. */
+int ldh_decompress(const uint8_t *in, size_t n, int fmt, const ldh_dict *dict,
+                   uint8_t *out, size_t cap, size_t *out_len, size_t *bytes_left,
+                   int *status);
+/* LibDeflate:Adler32 (LD:401-442) */
+int ldh_adler32(const uint8_t *s, size_t n, uint32_t *adler);
+/* LibDeflate:EncodeForPrint (LD:3311-3353); out needs (8n+5)/6 bytes. */
+int ldh_print6_encode(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                      size_t *out_len);
+/* LibDeflate:DecodeForPrint (LD:3365-3417); *ok = 0 stands for the nil return. */
+int ldh_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                      size_t *out_len, int *ok);
+
+/* ---- batched forms (the "batched entry point" of the north star) --------------
+ * Stream s is in_base[in_off[s] .. in_off[s+1]).  Its result goes to
+ * out_base + s*out_stride (out_stride % 16 == 0), length out_len[s].
+ * Host-pointer forms copy in/out and synchronise; *_dev forms take DEVICE pointers for
+ * every array argument and only enqueue.  level must be 0..9 for *_dev (host forms also
+ * accept LDH_LEVEL_DEFAULT and resolve it per stream). */
+int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
+                       int level, int strategy, const ldh_dict *dict, uint8_t *out_base,
+                       size_t out_stride, uint32_t *out_len, uint8_t *pad_bits);
+int ldh_compress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                           size_t max_in_len, int fmt, int level, int strategy,
+                           const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
+                           uint32_t *d_out_len, uint8_t *d_pad_bits);
+
+int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
+                         const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
+                         uint32_t *out_len, uint32_t *bytes_left, int32_t *status);
+int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                             int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
+                             uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status);
+
+int ldh_adler32_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                      uint32_t *adler);
+int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                          uint32_t *d_adler);
+
+int ldh_print6_encode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                            uint8_t *out_base, size_t out_stride, uint32_t *out_len);
+int ldh_print6_encode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                                uint8_t *d_out, size_t out_stride, uint32_t *d_out_len);
+/* ok[s] = 0 stands for DecodeForPrint's nil. */
+int ldh_print6_decode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                            uint8_t *out_base, size_t out_stride, uint32_t *out_len,
+                            uint8_t *ok);
+int ldh_print6_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                                uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
+                                uint8_t *d_ok);
+
+/* ---- measurement support (bench.py) -------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the library
+ * stream; ldh_profile_get returns the accumulated milliseconds and launch count of one
+ * kernel by name since the last ldh_profile_reset.  No reference counterpart. */
+int ldh_profile_enable(int on);
+int ldh_profile_reset(void);
+int ldh_profile_count(void);
+int ldh_profile_get(int index, char *name, size_t name_cap, double *ms, uint64_t *launches);
+/* hipEvent pair on the library stream for whole-pipeline timing */
+int ldh_timer_start(void);
+int ldh_timer_stop(double *ms);
+
+/* ---- test / inspection hooks (no reference counterpart; used by tests/ only) --
+ * Copies intermediate products of the last ldh_compress_batch* call for stream s to
+ * host memory.  what: 0 prev-link deltas (uint16 per virtual position), 1 per-position
+ * best match (uint32: len<<16|dist), 2 tokens (uint32), 3 block table (opaque bytes). */
+int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's method table (LibDeflate.lua:2039-2112, 2742-2823,
+401, 493, 3311, 3365) over libdeflate_hip.so.
+
+The reference's host language (Lua / LuaJIT) is not present in the build image, so the
+operator interface is restated in Python; `lua/LibDeflate.lua` is the LuaJIT-FFI shim a
+maintainer would load instead.  Method names, argument order, return
+tuples and usage-error strings follow the reference; Lua's `nil` is Python's `None`,
+strings are `bytes`.
+"""
+import ctypes as C
+
+from . import _native as N
+
+_STRATEGY = {None: 0, "fixed": 1, "huffman_only": 2, "dynamic": 3}
+
+
+def _lua_type(v):
+    if v is None:
+        return "nil"
+    if isinstance(v, (bytes, bytearray, str)):
+        return "string"
+    if isinstance(v, bool):
+        return "boolean"
+    if isinstance(v, (int, float)):
+        return "number"
+    if isinstance(v, (dict, Dictionary)):
+        return "table"
+    if callable(v):
+        return "function"
+    return "userdata"
+
+
+class Dictionary(object):
+    """Preset dictionary object (LibDeflate.lua:531-595): same visible fields
+    (adler32, strlen, string_table); the hash_tables of the reference live on the device
+    as the trigram chains that k_sort_links builds over dict ++ input."""
+
+    def __init__(self, data, adler32):
+        self.adler32 = adler32
+        self.strlen = len(data)
+        self.string_table = bytes(data)
+        self.hash_tables = {}
+        self._handle = None
+
+    def handle(self):
+        if self._handle is None:
+            N.init()
+            buf = (C.c_ubyte * len(self.string_table)).from_buffer_copy(self.string_table)
+            h = N.lib.ldh_dict_create(buf, len(self.string_table))
+            if not h:
+                raise N.LdhError((N.lib.ldh_last_error() or b"").decode())
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle:
+                N.lib.ldh_dict_free(self._handle)
+        except Exception:
+            pass
+
+
+def _is_valid_dictionary(d):  # LibDeflate.lua:602-615
+    if not isinstance(d, Dictionary):
+        return False, "'dictionary' - table expected got '%s'." % _lua_type(d)
+    if (not isinstance(d.adler32, (int, float)) or not isinstance(d.string_table, (bytes, bytearray))
+            or not isinstance(d.strlen, int) or d.strlen <= 0 or d.strlen > 32768
+            or d.strlen != len(d.string_table) or not isinstance(d.hash_tables, dict)):
+        return False, "'dictionary' - corrupted dictionary."
+    return True, ""
+
+
+def _is_valid_arguments(s, check_dictionary=False, dictionary=None, check_configs=False, configs=None):
+    # LibDeflate.lua:679-714
+    if not isinstance(s, (bytes, bytearray)):
+        return False, "'str' - string expected got '%s'." % _lua_type(s)
+    if check_dictionary:
+        ok, err = _is_valid_dictionary(dictionary)
+        if not ok:
+            return False, err
+    if check_configs:
+        if configs is not None and not isinstance(configs, dict):
+            return False, "'configs' - nil or table expected got '%s'." % _lua_type(configs)
+        if isinstance(configs, dict):
+            for k, v in configs.items():
+                if k != "level" and k != "strategy":
+                    return False, "'configs' - unsupported table key in the configs: '%s'." % k
+                if k == "level" and not (isinstance(v, int) and not isinstance(v, bool) and 0 <= v <= 9):
+                    return False, "'configs' - unsupported 'level': %s." % v
+                if k == "strategy" and v not in ("fixed", "huffman_only", "dynamic"):
+                    return False, "'configs' - unsupported 'strategy': '%s'." % v
+    return True, ""
+
+
+class UsageError(Exception):
+    """Lua's error(msg, 2) for argument errors."""
+
+
+def _buf(b):
+    return (C.c_ubyte * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
+
+
+class _LibDeflate(object):
+    _VERSION = "1.0.2-release"
+    _MAJOR = "LibDeflate"
+    _MINOR = 3
+
+    # -- LibDeflate.lua:401-442
+    def Adler32(self, s):
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError("Usage: LibDeflate:Adler32(str): 'str' - string expected got '%s'." % _lua_type(s))
+        N.init()
+        out = C.c_uint32()
+        N.check(N.lib.ldh_adler32(_buf(s), len(s), C.byref(out)))
+        return out.value
+
+    # -- LibDeflate.lua:493-596
+    def CreateDictionary(self, s, strlen, adler32):
+        pre = "Usage: LibDeflate:CreateDictionary(str, strlen, adler32):"
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError(pre + " 'str' - string expected got '%s'." % _lua_type(s))
+        if _lua_type(strlen) != "number":
+            raise UsageError(pre + " 'strlen' - number expected got '%s'." % _lua_type(strlen))
+        if _lua_type(adler32) != "number":
+            raise UsageError(pre + " 'adler32' - number expected got '%s'." % _lua_type(adler32))
+        if strlen != len(s):
+            raise UsageError(pre + " 'strlen' does not match the actual length of 'str'. 'strlen': %u, '#str': %u ."
+                             " Please check if 'str' is modified unintentionally." % (strlen, len(s)))
+        if strlen == 0:
+            raise UsageError(pre + " 'str' - Empty string is not allowed.")
+        if strlen > 32768:
+            raise UsageError(pre + " 'str' - string longer than 32768 bytes is not allowed. Got %d bytes." % strlen)
+        actual = self.Adler32(s)
+        if (adler32 % 4294967296) != (actual % 4294967296):
+            raise UsageError(pre + " 'adler32' does not match the actual adler32 of 'str'. 'adler32': %u,"
+                             " 'Adler32(str)': %u . Please check if 'str' is modified unintentionally."
+                             % (adler32 % 4294967296, actual))
+        return Dictionary(s, adler32)
+
+    # -- LibDeflate.lua:1960-2024
+    def _compress(self, s, fmt, dictionary, configs):
+        N.init()
+        level = -1
+        strategy = 0
+        if configs:
+            if configs.get("level") is not None:
+                level = configs["level"]
+            strategy = _STRATEGY[configs.get("strategy")]
+        cap = N.lib.ldh_compress_bound(len(s))
+        out = (C.c_ubyte * cap)()
+        ol = C.c_size_t()
+        pb = C.c_int()
+        N.check(N.lib.ldh_compress(_buf(s), len(s), fmt, level, strategy,
+                                   dictionary.handle() if dictionary is not None else None, out, cap,
+                                   C.byref(ol), C.byref(pb)))
+        return bytes(out[: ol.value]), pb.value
+
+    def CompressDeflate(self, s, configs=None):
+        ok, err = _is_valid_arguments(s, False, None, True, configs)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:CompressDeflate(str, configs): " + err)
+        return self._compress(s, 0, None, configs)
+
+    def CompressDeflateWithDict(self, s, dictionary, configs=None):
+        ok, err = _is_valid_arguments(s, True, dictionary, True, configs)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:CompressDeflateWithDict(str, dictionary, configs): " + err)
+        return self._compress(s, 0, dictionary, configs)
+
+    def CompressZlib(self, s, configs=None):
+        ok, err = _is_valid_arguments(s, False, None, True, configs)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:CompressZlib(str, configs): " + err)
+        return self._compress(s, 1, None, configs)
+
+    def CompressZlibWithDict(self, s, dictionary, configs=None):
+        ok, err = _is_valid_arguments(s, True, dictionary, True, configs)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:CompressZlibWithDict(str, dictionary, configs): " + err)
+        return self._compress(s, 1, dictionary, configs)
+
+    # -- LibDeflate.lua:2648-2727: (data, bytes_left) or (None, status)
+    def _decompress(self, s, fmt, dictionary):
+        N.init()
+        cap = max(64, 4 * len(s) + 64)
+        h = dictionary.handle() if dictionary is not None else None
+        while True:
+            out = (C.c_ubyte * cap)()
+            ol, bl, st = C.c_size_t(), C.c_size_t(), C.c_int()
+            N.check(N.lib.ldh_decompress(_buf(s), len(s), fmt, h, out, cap, C.byref(ol), C.byref(bl), C.byref(st)))
+            if st.value == 1:  # LDH_STATUS_OUTPUT_FULL: Lua strings simply grow
+                cap *= 4
+                continue
+            if st.value != 0:
+                return None, st.value
+            return bytes(out[: ol.value]), bl.value
+
+    def DecompressDeflate(self, s):
+        ok, err = _is_valid_arguments(s)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:DecompressDeflate(str): " + err)
+        return self._decompress(s, 0, None)
+
+    def DecompressDeflateWithDict(self, s, dictionary):
+        ok, err = _is_valid_arguments(s, True, dictionary)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:DecompressDeflateWithDict(str, dictionary): " + err)
+        return self._decompress(s, 0, dictionary)
+
+    def DecompressZlib(self, s):
+        ok, err = _is_valid_arguments(s)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:DecompressZlib(str): " + err)
+        return self._decompress(s, 1, None)
+
+    def DecompressZlibWithDict(self, s, dictionary):
+        ok, err = _is_valid_arguments(s, True, dictionary)
+        if not ok:
+            raise UsageError("Usage: LibDeflate:DecompressZlibWithDict(str, dictionary): " + err)
+        return self._decompress(s, 1, dictionary)
+
+    # -- LibDeflate.lua:3311-3417
+    def EncodeForPrint(self, s):
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError("Usage: LibDeflate:EncodeForPrint(str): 'str' - string expected got '%s'." % _lua_type(s))
+        N.init()
+        cap = (len(s) * 8 + 5) // 6 + 16
+        out = (C.c_ubyte * cap)()
+        ol = C.c_size_t()
+        N.check(N.lib.ldh_print6_encode(_buf(s), len(s), out, cap, C.byref(ol)))
+        return bytes(out[: ol.value])
+
+    def DecodeForPrint(self, s):
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError("Usage: LibDeflate:DecodeForPrint(str): 'str' - string expected got '%s'." % _lua_type(s))
+        N.init()
+        cap = len(s) + 16
+        out = (C.c_ubyte * cap)()
+        ol = C.c_size_t()
+        ok = C.c_int()
+        N.check(N.lib.ldh_print6_decode(_buf(s), len(s), out, cap, C.byref(ol), C.byref(ok)))
+        if not ok.value:
+            return None
+        return bytes(out[: ol.value])
+
+
+LibDeflate = _LibDeflate()

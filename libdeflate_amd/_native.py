@@ -1,0 +1,87 @@
+"""ctypes binding of libdeflate_hip.so (include/libdeflate_hip.h).
+
+The HIP library is the product path; there is no CPU fallback.  Importing this module
+fails loudly when the shared object has not been built (run `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C libdeflate_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libdeflate_hip.so")
+
+if not os.path.exists(SO_PATH):
+    raise ImportError(
+        "libdeflate_hip.so is missing (%s). Build it with `make -C libdeflate_amd/csrc`; "
+        "this package has no CPU fallback." % SO_PATH)
+
+lib = C.CDLL(SO_PATH)
+
+u8p, u32p, u64p, i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+sz = C.c_size_t
+
+_SIGS = {
+    "ldh_init": (C.c_int, [C.c_int]),
+    "ldh_shutdown": (None, []),
+    "ldh_device_count": (C.c_int, []),
+    "ldh_last_error": (C.c_char_p, []),
+    "ldh_stream": (C.c_void_p, []),
+    "ldh_sync": (C.c_int, []),
+    "ldh_compress_bound": (sz, [sz]),
+    "ldh_dict_create": (C.c_void_p, [u8p, sz]),
+    "ldh_dict_free": (None, [C.c_void_p]),
+    "ldh_dict_adler32": (C.c_uint32, [C.c_void_p]),
+    "ldh_dict_len": (sz, [C.c_void_p]),
+    "ldh_compress": (C.c_int, [u8p, sz, C.c_int, C.c_int, C.c_int, C.c_void_p, u8p, sz,
+                               C.POINTER(sz), C.POINTER(C.c_int)]),
+    "ldh_decompress": (C.c_int, [u8p, sz, C.c_int, C.c_void_p, u8p, sz, C.POINTER(sz), C.POINTER(sz),
+                                 C.POINTER(C.c_int)]),
+    "ldh_adler32": (C.c_int, [u8p, sz, C.POINTER(C.c_uint32)]),
+    "ldh_print6_encode": (C.c_int, [u8p, sz, u8p, sz, C.POINTER(sz)]),
+    "ldh_print6_decode": (C.c_int, [u8p, sz, u8p, sz, C.POINTER(sz), C.POINTER(C.c_int)]),
+    "ldh_compress_batch": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_int, C.c_int, C.c_void_p, u8p, sz, u32p, u8p]),
+    "ldh_compress_batch_dev": (C.c_int, [u8p, u64p, sz, sz, C.c_int, C.c_int, C.c_int, C.c_void_p, u8p, sz,
+                                         u32p, u8p]),
+    "ldh_decompress_batch": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_void_p, u8p, sz, u32p, u32p, i32p]),
+    "ldh_decompress_batch_dev": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_void_p, u8p, sz, u32p, u32p, i32p]),
+    "ldh_adler32_batch": (C.c_int, [u8p, u64p, sz, u32p]),
+    "ldh_adler32_batch_dev": (C.c_int, [u8p, u64p, sz, u32p]),
+    "ldh_print6_encode_batch": (C.c_int, [u8p, u64p, sz, u8p, sz, u32p]),
+    "ldh_print6_encode_batch_dev": (C.c_int, [u8p, u64p, sz, u8p, sz, u32p]),
+    "ldh_print6_decode_batch": (C.c_int, [u8p, u64p, sz, u8p, sz, u32p, u8p]),
+    "ldh_print6_decode_batch_dev": (C.c_int, [u8p, u64p, sz, u8p, sz, u32p, u8p]),
+    "ldh_profile_enable": (C.c_int, [C.c_int]),
+    "ldh_profile_reset": (C.c_int, []),
+    "ldh_profile_count": (C.c_int, []),
+    "ldh_profile_get": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "ldh_timer_start": (C.c_int, []),
+    "ldh_timer_stop": (C.c_int, [C.POINTER(C.c_double)]),
+    "ldh_debug_fetch": (C.c_int, [C.c_int, sz, C.c_void_p, sz, C.POINTER(sz)]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _f = getattr(lib, _name)  # AttributeError here = header/library mismatch
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class LdhError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise LdhError("libdeflate_hip error %d: %s" % (rc, (lib.ldh_last_error() or b"").decode()))
+
+
+_inited = None
+
+
+def init(device=0):
+    global _inited
+    if _inited == device:
+        return
+    check(lib.ldh_init(device))
+    _inited = device

@@ -1,0 +1,684 @@
+// k_huffman.h -- north-star parts (2) histograms, (3) Huffman build + header RLE + block
+// choice, (4) bit packing.
+//
+//   k_histogram  LD:1436-1440,1470,1481   LDS-atomic literal/length and distance counts
+//   k_huffman    LD:968-1085, 1099-1174, 1491-1567, 1646-1670: one wavefront per block
+//   k_plan       LD:1718-1727, 1867-1894, 1963-1965, 1970-2024: serial over a stream's
+//                blocks (stored-block padding depends on the absolute bit position)
+//   k_bitpack    LD:736-832, 1571-1640, 1675-1710, 1732-1750: prefix scan of code lengths,
+//                bits OR-ed into an LDS image, whole words stored coalesced
+#pragma once
+#include "ldh_common.h"
+
+namespace ldh {
+
+// ------------------------------------------------------------------ k_histogram
+__global__ __launch_bounds__(256) void k_histogram(Batch B) {
+  __shared__ uint32_t h[320];
+  const uint32_t s = blockIdx.x / B.max_blocks, b = blockIdx.x % B.max_blocks;
+  const uint32_t n = stream_len(B, s);
+  if (b >= num_blocks(n)) return;
+  BlockInfo *bi = &B.blocks[(size_t)s * B.max_blocks + b];
+  const uint32_t *tok = B.bufA + (size_t)s * B.nvp + (block_start(b) - 1);
+  const uint32_t ntok = bi->ntok;
+  for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ntok; i += 256) {
+    const uint32_t t = tok[i];
+    if (t & kTokMatch) {
+      atomicAdd(&h[length_code(tok_len(t)).code], 1u);
+      atomicAdd(&h[286 + dist_code(tok_dist(t)).code], 1u);
+    } else {
+      atomicAdd(&h[t], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 286; i += 256) bi->lcount[i] = h[i] + (i == 256 ? 1u : 0u);  // EOB, LD:1481
+  for (uint32_t i = threadIdx.x; i < 30; i += 256) bi->dcount[i] = h[286 + i];
+}
+
+// ------------------------------------------------------------------ k_huffman
+struct HuffScratch {
+  uint32_t w[576];  // weight, later depth (LD:978)
+  int16_t sym[576], left[576], right[576];
+  int16_t leafs[288], heap[292], fifo[576];
+  uint32_t cnt[288];  // counts of the alphabet being built
+  uint8_t len[288];
+  uint16_t code[288];
+  int bl_count[17];
+};
+
+// LD:863-903
+__device__ inline int hs_pop(HuffScratch &S, int heap_size) {
+  const int top = S.heap[1];
+  const int e = S.heap[heap_size];
+  const uint32_t value = S.w[e];
+  S.heap[1] = (int16_t)e;
+  S.heap[heap_size] = (int16_t)top;
+  heap_size--;
+  int pos = 1, l = 2, r = 3;
+  while (l <= heap_size) {
+    const int lc = S.heap[l];
+    if (r <= heap_size && S.w[S.heap[r]] < S.w[lc]) {
+      const int rc = S.heap[r];
+      if (S.w[rc] < value) {
+        S.heap[r] = (int16_t)e;
+        S.heap[pos] = (int16_t)rc;
+        pos = r;
+      } else
+        break;
+    } else {
+      if (S.w[lc] < value) {
+        S.heap[l] = (int16_t)e;
+        S.heap[pos] = (int16_t)lc;
+        pos = l;
+      } else
+        break;
+    }
+    l = pos * 2;
+    r = l + 1;
+  }
+  return top;
+}
+// LD:842-856
+__device__ inline void hs_push(HuffScratch &S, int e, int heap_size) {
+  heap_size++;
+  S.heap[heap_size] = (int16_t)e;
+  const uint32_t value = S.w[e];
+  int pos = heap_size, parent = pos / 2;
+  while (parent >= 1 && S.w[S.heap[parent]] > value) {
+    const int t = S.heap[parent];
+    S.heap[parent] = (int16_t)e;
+    S.heap[pos] = (int16_t)t;
+    pos = parent;
+    parent /= 2;
+  }
+}
+
+// GetHuffmanBitlenAndCode (LD:968-1085) over S.cnt[0..nsym); results in S.len / S.code.
+// Called by the whole wavefront; the leaf sort is done by all lanes, the heap by lane 0.
+// Returns max_non_zero_bitlen_symbol (-1 if no symbol).
+__device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lane) {
+  for (int i = lane; i < nsym; i += kWave) {
+    S.len[i] = 0;
+    S.code[i] = 0;
+  }
+  // rank of every used symbol in (count, symbol) order (LD:953-955, 1002)
+  int nleaf = 0;
+  for (int base = 0; base < nsym; base += kWave) {
+    const int i = base + (int)lane;
+    const uint32_t ci = i < nsym ? S.cnt[i] : 0;
+    if (ci) {
+      int rank = 0;
+      for (int j = 0; j < nsym; j++) {
+        const uint32_t cj = S.cnt[j];
+        rank += (cj != 0 && (cj < ci || (cj == ci && j < i)));
+      }
+      S.leafs[rank] = (int16_t)i;
+    }
+    nleaf += __popcll(__ballot(ci != 0));
+  }
+  __syncthreads();
+  int max_nz = -1;
+  if (lane == 0) {
+    if (nleaf == 1) {  // LD:992-1000
+      const int sy = S.leafs[0];
+      S.len[sy] = 1;
+      S.code[sy] = 0;
+      max_nz = sy;
+    } else if (nleaf >= 2) {
+      for (int i = 0; i < nleaf; i++) {
+        const int sy = S.leafs[i];
+        S.w[i] = S.cnt[sy];
+        S.sym[i] = (int16_t)sy;
+        S.left[i] = S.right[i] = -1;
+        S.heap[i + 1] = (int16_t)i;
+      }
+      int heap_size = nleaf, nnodes = nleaf;
+      while (heap_size > 1) {  // LD:1006-1015
+        const int l = hs_pop(S, heap_size);
+        heap_size--;
+        const int r = hs_pop(S, heap_size);
+        heap_size--;
+        S.w[nnodes] = S.w[l] + S.w[r];
+        S.sym[nnodes] = -1;
+        S.left[nnodes] = (int16_t)l;
+        S.right[nnodes] = (int16_t)r;
+        hs_push(S, nnodes, heap_size);
+        nnodes++;
+        heap_size++;
+      }
+      for (int i = 0; i <= 16; i++) S.bl_count[i] = 0;
+      int fifo_size = 1, index = 0, overflow = 0;
+      S.fifo[0] = S.heap[1];
+      S.w[S.heap[1]] = 0;
+      while (index < fifo_size) {  // LD:1025-1053
+        const int e = S.fifo[index];
+        int bitlen = (int)S.w[e];
+        if (S.left[e] >= 0) {
+          S.fifo[fifo_size++] = S.left[e];
+          S.w[S.left[e]] = bitlen + 1;
+        }
+        if (S.right[e] >= 0) {
+          S.fifo[fifo_size++] = S.right[e];
+          S.w[S.right[e]] = bitlen + 1;
+        }
+        index++;
+        if (bitlen > max_bitlen) {
+          overflow++;
+          bitlen = max_bitlen;
+        }
+        if (S.sym[e] >= 0) {
+          S.len[S.sym[e]] = (uint8_t)bitlen;
+          if (S.sym[e] > max_nz) max_nz = S.sym[e];
+          S.bl_count[bitlen]++;
+        }
+      }
+      if (overflow > 0) {  // LD:1057-1079
+        int bitlen;
+        do {
+          bitlen = max_bitlen - 1;
+          while (bitlen > 0 && S.bl_count[bitlen] == 0) bitlen--;
+          if (bitlen <= 0) break;
+          S.bl_count[bitlen]--;
+          S.bl_count[bitlen + 1] += 2;
+          S.bl_count[max_bitlen]--;
+          overflow -= 2;
+        } while (overflow > 0);
+        index = 0;
+        for (bitlen = max_bitlen; bitlen >= 1; bitlen--) {
+          int k = S.bl_count[bitlen];
+          while (k > 0) {
+            S.len[S.leafs[index]] = (uint8_t)bitlen;
+            k--;
+            index++;
+          }
+        }
+      }
+      // LD:913-948 canonical codes, bit-reversed
+      int next_code[17];
+      int code = 0;
+      for (int bl = 1; bl <= max_bitlen; bl++) {
+        code = (code + S.bl_count[bl - 1]) * 2;
+        next_code[bl] = code;
+      }
+      for (int sy = 0; sy < nsym; sy++) {
+        const int len = S.len[sy];
+        if (len) {
+          const uint32_t c = (uint32_t)next_code[len]++;
+          S.code[sy] = (uint16_t)(__brev(c) >> (32 - len));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  max_nz = __shfl(max_nz, 0);
+  return max_nz;
+}
+
+__device__ inline int rle_extra_bitlen(int c) { return c == 16 ? 2 : (c == 17 ? 3 : 7); }
+
+__global__ __launch_bounds__(kWave) void k_huffman(Batch B) {
+  __shared__ HuffScratch S;
+  __shared__ uint8_t s_llen[286], s_dlen[30];
+  __shared__ uint32_t s_rlecnt[19];
+  const uint32_t s = blockIdx.x / B.max_blocks, b = blockIdx.x % B.max_blocks;
+  const uint32_t n = stream_len(B, s);
+  if (b >= num_blocks(n)) return;
+  const uint32_t lane = threadIdx.x;
+  BlockInfo *bi = &B.blocks[(size_t)s * B.max_blocks + b];
+
+  // literal/length tree (LD:1493)
+  for (int i = lane; i < 286; i += kWave) S.cnt[i] = bi->lcount[i];
+  __syncthreads();
+  const int max_l = huff_build(S, 286, 15, lane);
+  uint64_t dyn = 0, fix = 0;
+  for (int i = lane; i < 286; i += kWave) {
+    const uint32_t c = S.cnt[i], l = S.len[i];
+    bi->l_len[i] = (uint8_t)l;
+    bi->l_code[i] = S.code[i];
+    s_llen[i] = (uint8_t)l;
+    const uint32_t eb = i > 256 ? len_extra_bits(i) : 0;
+    dyn += (uint64_t)c * (l + eb);
+    fix += (uint64_t)c * (fixed_lit_bits(i) + eb);
+  }
+  __syncthreads();
+  // distance tree (LD:1495)
+  for (int i = lane; i < 30; i += kWave) S.cnt[i] = bi->dcount[i];
+  __syncthreads();
+  int max_d = huff_build(S, 30, 15, lane);
+  for (int i = lane; i < 30; i += kWave) {
+    const uint32_t c = S.cnt[i], l = S.len[i];
+    bi->d_len[i] = (uint8_t)l;
+    bi->d_code[i] = S.code[i];
+    s_dlen[i] = (uint8_t)l;
+    const uint32_t eb = dist_extra_bits(i);
+    dyn += (uint64_t)c * (l + eb);
+    fix += (uint64_t)c * (5 + eb);
+  }
+  for (int i = lane; i < 19; i += kWave) s_rlecnt[i] = 0;
+  __syncthreads();
+
+  // RunLengthEncodeHuffmanBitlen (LD:1099-1174), serial: <= 318 steps
+  int nrle = 0;
+  uint32_t rle_bits_extra = 0;
+  if (lane == 0) {
+    int prev = -1, count = 0;
+    int md = max_d < 0 ? 0 : max_d;
+    const int max_code = max_l + md + 1;
+    for (int code = 0; code <= max_code + 1; code++) {
+      const int len = code <= max_l ? (int)s_llen[code]
+                                    : (code <= max_code ? (int)s_dlen[code - max_l - 1] : -2);
+      if (len == prev) {
+        count++;
+        if (len != 0 && count == 6) {
+          bi->rle_sym[nrle] = 16;
+          bi->rle_extra[nrle] = 3;
+          nrle++;
+          s_rlecnt[16]++;
+          count = 0;
+        } else if (len == 0 && count == 138) {
+          bi->rle_sym[nrle] = 18;
+          bi->rle_extra[nrle] = 127;
+          nrle++;
+          s_rlecnt[18]++;
+          count = 0;
+        }
+      } else {
+        if (count == 1) {
+          bi->rle_sym[nrle] = (uint8_t)prev;
+          bi->rle_extra[nrle] = 0;
+          nrle++;
+          s_rlecnt[prev]++;
+        } else if (count == 2) {
+          bi->rle_sym[nrle] = (uint8_t)prev;
+          bi->rle_extra[nrle] = 0;
+          nrle++;
+          bi->rle_sym[nrle] = (uint8_t)prev;
+          bi->rle_extra[nrle] = 0;
+          nrle++;
+          s_rlecnt[prev] += 2;
+        } else if (count >= 3) {
+          const int rc = prev != 0 ? 16 : (count <= 10 ? 17 : 18);
+          bi->rle_sym[nrle] = (uint8_t)rc;
+          bi->rle_extra[nrle] = (uint8_t)(count <= 10 ? count - 3 : count - 11);
+          nrle++;
+          s_rlecnt[rc]++;
+        }
+        prev = len;
+        if (len > 0) {
+          bi->rle_sym[nrle] = (uint8_t)len;
+          bi->rle_extra[nrle] = 0;
+          nrle++;
+          s_rlecnt[len]++;
+          count = 0;
+        } else {
+          count = 1;
+        }
+      }
+    }
+    bi->nrle = (uint16_t)nrle;
+  }
+  __syncthreads();
+  // code-length code (LD:1504)
+  for (int i = lane; i < 19; i += kWave) S.cnt[i] = s_rlecnt[i];
+  __syncthreads();
+  huff_build(S, 19, 7, lane);
+  if (lane < 19) {
+    bi->cl_len[lane] = S.len[lane];
+    bi->cl_code[lane] = (uint8_t)S.code[lane];
+    const uint32_t c = S.cnt[lane];
+    const uint32_t eb = lane >= 16 ? (uint32_t)rle_extra_bitlen((int)lane) : 0;
+    rle_bits_extra = c * (S.len[lane] + eb);
+  }
+  // wave reductions
+  for (int off = 32; off > 0; off >>= 1) {
+    dyn += __shfl_down(dyn, off);
+    fix += __shfl_down(fix, off);
+    rle_bits_extra += __shfl_down(rle_bits_extra, off);
+  }
+  if (lane == 0) {
+    const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 0;
+    for (int i = 1; i <= 19; i++)
+      if (S.len[order[i - 1]] != 0) hclen = i;
+    hclen -= 4;  // LD:1513
+    int hdist = max_d + 1 - 1;
+    if (hdist < 0) hdist = 0;
+    bi->hclen = (uint8_t)hclen;
+    bi->hlit = (uint8_t)(max_l + 1 - 257);
+    bi->hdist = (uint8_t)hdist;
+    bi->dyn_bits = (uint32_t)(17 + 3 * (hclen + 4) + rle_bits_extra + dyn);  // LD:1526-1567
+    bi->fix_bits = (uint32_t)(3 + fix);                                       // LD:1646-1670
+  }
+}
+
+// ------------------------------------------------------------------ k_plan
+// One lane per stream.  LD:1865-1894 block choice (ties: store, then fixed, then dynamic),
+// running total_bitlen, final padding / zlib trailer sizes.  Also zeroes the output words
+// that two blocks share so that k_bitpack may OR into them.
+__global__ void k_plan(Batch B) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.count) return;
+  const uint32_t n = stream_len(B, s);
+  const uint32_t nblk = num_blocks(n);
+  uint32_t *out32 = (uint32_t *)(B.out + (size_t)s * B.out_stride);
+  uint64_t total = 0;
+  if (B.fmt == 1) total = B.dict ? 48 : 16;  // CMF, FLG, DICTID (LD:1976-2001)
+  for (uint32_t b = 0; b < nblk; b++) {
+    BlockInfo *bi = &B.blocks[(size_t)s * B.max_blocks + b];
+    const uint32_t bs = block_start(b), be = block_end(b, n);
+    const uint64_t t3 = total + 3;
+    const uint64_t store = 3 + (8 - t3 % 8) % 8 + 32 + (uint64_t)(be + 1 - bs) * 8;  // LD:1718-1727
+    uint32_t type;
+    uint64_t bits;
+    if (B.level == 0) {
+      type = 0;
+      bits = store;
+    } else {
+      const uint64_t fix = bi->fix_bits, dyn = bi->dyn_bits;
+      uint64_t mn = store;
+      if (fix < mn) mn = fix;
+      if (dyn < mn) mn = dyn;
+      if (B.strategy != 1 && B.strategy != 3 && store == mn) {
+        type = 0;
+        bits = store;
+      } else if (B.strategy != 3 && (B.strategy == 1 || fix == mn)) {
+        type = 1;
+        bits = fix;
+      } else {
+        type = 2;
+        bits = dyn;
+      }
+    }
+    bi->type = (uint8_t)type;
+    bi->bit_start = total;
+    bi->bit_end = total + bits;
+    out32[total >> 5] = 0;
+    // stored block: its header ends mid-word and raw bytes follow in the same word
+    if (type == 0) out32[(total + 3 + (8 - t3 % 8) % 8 + 32) >> 5] = 0;
+    total += bits;
+  }
+  out32[total >> 5] = 0;
+  const uint32_t pad = (uint32_t)((8 - total % 8) % 8);
+  uint64_t bytes = (total + pad) / 8;
+  if (B.fmt == 1) {
+    out32[(total + pad + 31) >> 5] = 0;  // trailer may end in a fresh word
+    bytes += 4;
+  }
+  B.out_len[s] = (uint32_t)bytes;
+  B.pad_bits[s] = (uint8_t)(B.fmt == 1 ? 0 : pad);
+}
+
+// ------------------------------------------------------------------ k_bitpack
+constexpr int kPackThreads = 256;
+constexpr int kPackItems = 4;                               // symbols per thread per round
+constexpr int kPackRound = kPackThreads * kPackItems;       // 1024 symbols, <= 48 bits each
+constexpr int kPackWords = (kPackRound * 48) / 32 + 8;      // LDS image of one round
+
+struct Packer {
+  uint32_t *img;        // LDS image, kPackWords words
+  uint32_t *scan;       // LDS scratch for the block scan, kPackThreads/64 + 1 words
+  uint32_t *out32;      // stream's output as words
+  uint64_t bitpos;      // absolute bit position of the next symbol (uniform)
+  uint64_t first_word;  // word index img[0] stands for
+  uint64_t block_first_word;  // first word of this deflate block (shared with predecessor)
+  bool block_first_partial;
+};
+
+// OR `nbits` (<= 57) bits of `val` into the LDS image at absolute bit position `pos`.
+__device__ inline void img_or(const Packer &P, uint64_t pos, uint64_t val, uint32_t nbits) {
+  if (!nbits) return;
+  const uint32_t rel = (uint32_t)(pos - P.first_word * 32);
+  const uint32_t w = rel >> 5, sh = rel & 31;
+  atomicOr(&P.img[w], (uint32_t)(val << sh));
+  if (sh + nbits > 32) {
+    const uint64_t hi = val >> (32 - sh);
+    atomicOr(&P.img[w + 1], (uint32_t)hi);
+    if (sh + nbits > 64) atomicOr(&P.img[w + 2], (uint32_t)(hi >> 32));
+  }
+}
+
+// All threads call this once per round with their symbols' (value, nbits); the round's
+// bits are appended at P.bitpos.  Completed words go to global memory.
+__device__ inline void pack_round(Packer &P, const uint64_t *val, const uint32_t *nb, bool last_round) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < kPackItems; k++) mine += nb[k];
+  uint32_t inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(inc, off);
+    if (lane >= (uint32_t)off) inc += t;
+  }
+  if (lane == 63) P.scan[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < kPackThreads / 64; w++) {
+    const uint32_t t = P.scan[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  uint64_t pos = P.bitpos + base + inc - mine;
+#pragma unroll
+  for (int k = 0; k < kPackItems; k++) {
+    img_or(P, pos, val[k], nb[k]);
+    pos += nb[k];
+  }
+  __syncthreads();
+  const uint64_t end = P.bitpos + tot;
+  // words [first_word, end/32) are complete; on the last round of the block also flush the tail
+  const uint64_t full_end = end >> 5;
+  const uint32_t nfull = (uint32_t)(full_end - P.first_word);
+  const uint32_t tail = (uint32_t)(end & 31);
+  for (uint32_t i = tid; i < nfull; i += kPackThreads) {
+    const uint64_t gw = P.first_word + i;
+    if (gw == P.block_first_word && P.block_first_partial)
+      atomicOr(&P.out32[gw], P.img[i]);
+    else
+      P.out32[gw] = P.img[i];
+  }
+  uint32_t carry = (tail || last_round) ? P.img[nfull] : 0;
+  __syncthreads();
+  if (last_round) {
+    if (tid == 0 && tail) atomicOr(&P.out32[full_end], carry);
+  }
+  // reset image: word 0 = carry (partial word), rest zero
+  for (uint32_t i = tid; i < (uint32_t)kPackWords; i += kPackThreads) P.img[i] = (i == 0 && !last_round) ? carry : 0;
+  P.first_word = full_end;
+  P.bitpos = end;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kPackThreads) void k_bitpack(Batch B) {
+  __shared__ uint32_t s_img[kPackWords];
+  __shared__ uint32_t s_scan[kPackThreads / 64 + 1];
+  const uint32_t s = blockIdx.x / B.max_blocks, b = blockIdx.x % B.max_blocks;
+  const uint32_t n = stream_len(B, s);
+  const uint32_t nblk = num_blocks(n);
+  if (b >= nblk) return;
+  const uint32_t tid = threadIdx.x;
+  const BlockInfo *bi = &B.blocks[(size_t)s * B.max_blocks + b];
+  const uint32_t bs = block_start(b), be = block_end(b, n);
+  const bool last = (b + 1 == nblk);
+  const uint32_t type = bi->type;
+  uint8_t *out = B.out + (size_t)s * B.out_stride;
+
+  Packer P;
+  P.img = s_img;
+  P.scan = s_scan;
+  P.out32 = (uint32_t *)out;
+  uint64_t start = bi->bit_start;
+  // stream prologue (zlib header) rides with block 0
+  const bool zhdr = (b == 0 && B.fmt == 1);
+  if (zhdr) start = 0;
+  P.bitpos = start;
+  P.first_word = start >> 5;
+  P.block_first_word = P.first_word;
+  P.block_first_partial = true;  // the block's first word may be shared; k_plan zeroed it
+  for (uint32_t i = tid; i < (uint32_t)kPackWords; i += kPackThreads) s_img[i] = 0;
+  __syncthreads();
+
+  uint64_t val[kPackItems];
+  uint32_t nb[kPackItems];
+
+  // ---- header symbols (few): produced by thread-serial lists, packed in rounds
+  // sequence: [zlib header bytes] BFINAL/BTYPE [store: pad, LEN, NLEN | dynamic: HLIT.. cl lens, rle codes]
+  {
+    // number of header items
+    uint32_t nh_z = zhdr ? (B.dict ? 6u : 2u) : 0u;
+    uint32_t nh = nh_z + 1;
+    if (type == 0) nh += 2;  // pad+LEN, NLEN
+    if (type == 2) nh += 1 + (bi->hclen + 4u) + bi->nrle;
+    for (uint32_t r0 = 0; r0 < nh; r0 += kPackRound) {
+#pragma unroll
+      for (int k = 0; k < kPackItems; k++) {
+        const uint32_t i = r0 + tid * kPackItems + k;
+        uint64_t v = 0;
+        uint32_t l = 0;
+        if (i < nh) {
+          if (i < nh_z) {
+            const uint32_t cmf = 0x78;
+            uint32_t flg = 2 * 64 + (B.dict ? 32 : 0);
+            flg += 31 - (cmf * 256 + flg) % 31;
+            if (i == 0) v = cmf;
+            else if (i == 1) v = flg;
+            else v = (B.dict_adler >> (8 * (5 - i))) & 0xFF;  // DICTID big-endian (LD:1988-2001)
+            l = 8;
+          } else {
+            const uint32_t j = i - nh_z;
+            if (j == 0) {
+              v = (last ? 1u : 0u) | (type << 1);
+              l = 3;
+            } else if (type == 0) {
+              const uint32_t size = be + 1 - bs;
+              if (j == 1) {  // LD:1737-1743 pad with ones, then LEN
+                const uint32_t pad = (uint32_t)((8 - (bi->bit_start + 3) % 8) % 8);
+                v = ((1u << pad) - 1u) | ((uint64_t)size << pad);
+                l = pad + 16;
+              } else {
+                v = (~size) & 0xFFFF;
+                l = 16;
+              }
+            } else {  // dynamic header LD:1585-1604
+              if (j == 1) {
+                v = (uint32_t)bi->hlit | ((uint32_t)bi->hdist << 5) | ((uint32_t)bi->hclen << 10);
+                l = 14;
+              } else if (j < 2 + bi->hclen + 4u) {
+                const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                v = bi->cl_len[order[j - 2]];
+                l = 3;
+              } else {
+                const uint32_t r = j - 2 - (bi->hclen + 4u);
+                const uint32_t c = bi->rle_sym[r];
+                const uint32_t cl = bi->cl_len[c];
+                v = bi->cl_code[c];
+                l = cl;
+                if (c >= 16) {
+                  v |= (uint64_t)bi->rle_extra[r] << cl;
+                  l += rle_extra_bitlen((int)c);
+                }
+              }
+            }
+          }
+        }
+        val[k] = v;
+        nb[k] = l;
+      }
+      pack_round(P, val, nb, false);
+    }
+  }
+
+  if (type == 0) {
+    // flush the header image, then raw bytes at the byte-aligned position (LD:1749)
+    for (int k = 0; k < kPackItems; k++) {
+      val[k] = 0;
+      nb[k] = 0;
+    }
+    pack_round(P, val, nb, true);
+    const uint64_t byte0 = P.bitpos >> 3;
+    const uint8_t *src = B.vbuf + (size_t)s * (B.nvp + kVPad) + B.dlen + (bs - 1);
+    const uint32_t size = be + 1 - bs;
+    for (uint32_t i = tid; i < size; i += kPackThreads) out[byte0 + i] = src[i];
+    P.bitpos += (uint64_t)size * 8;
+    __syncthreads();
+    if (!last) return;
+    // restart the image at the new position for the trailer
+    P.first_word = P.bitpos >> 5;
+    P.block_first_word = P.first_word;
+  } else {
+    const uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
+    const uint32_t ntok = bi->ntok;
+    const uint32_t nsym = ntok + 1;  // + EOB
+    for (uint32_t r0 = 0; r0 < nsym; r0 += kPackRound) {
+#pragma unroll
+      for (int k = 0; k < kPackItems; k++) {
+        const uint32_t i = r0 + tid * kPackItems + k;
+        uint64_t v = 0;
+        uint32_t l = 0;
+        if (i < nsym) {
+          const uint32_t t = i < ntok ? tok[i] : 256u;
+          if (t & kTokMatch) {
+            const Code lc = length_code(tok_len(t));
+            const Code dc = dist_code(tok_dist(t));
+            uint32_t lcode, llen, dcode, dlen;
+            if (type == 2) {
+              lcode = bi->l_code[lc.code];
+              llen = bi->l_len[lc.code];
+              dcode = bi->d_code[dc.code];
+              dlen = bi->d_len[dc.code];
+            } else {  // fixed codes LD:2826-2849
+              llen = fixed_lit_bits(lc.code);
+              const uint32_t c = lc.code <= 279 ? (lc.code - 256) : (0xC0 + lc.code - 280);
+              lcode = __brev(c) >> (32 - llen);
+              dlen = 5;
+              dcode = __brev(dc.code) >> 27;
+            }
+            v = lcode;
+            l = llen;
+            v |= (uint64_t)lc.eval << l;
+            l += lc.ebits;
+            v |= (uint64_t)dcode << l;
+            l += dlen;
+            v |= (uint64_t)dc.eval << l;
+            l += dc.ebits;
+          } else {
+            if (type == 2) {
+              v = bi->l_code[t];
+              l = bi->l_len[t];
+            } else {
+              l = fixed_lit_bits(t);
+              const uint32_t c = t <= 143 ? (0x30 + t) : (t <= 255 ? (0x190 + t - 144) : (t - 256));
+              v = __brev(c) >> (32 - l);
+            }
+          }
+        }
+        val[k] = v;
+        nb[k] = l;
+      }
+      pack_round(P, val, nb, (r0 + kPackRound >= nsym) && !last);
+    }
+    if (!last) return;
+  }
+  // stream epilogue: pad to a byte with ones (LD:796-812); zlib: Adler-32 big-endian (LD:2004-2020)
+  {
+    for (int k = 0; k < kPackItems; k++) {
+      val[k] = 0;
+      nb[k] = 0;
+    }
+    if (tid == 0) {
+      const uint32_t pad = (uint32_t)((8 - P.bitpos % 8) % 8);
+      val[0] = (1u << pad) - 1u;
+      nb[0] = pad;
+      if (B.fmt == 1) {
+        const uint32_t ad = B.adler[s];
+        val[1] = __builtin_bswap32(ad);
+        nb[1] = 32;
+      }
+    }
+    pack_round(P, val, nb, true);
+  }
+}
+
+}  // namespace ldh

@@ -1,0 +1,438 @@
+// k_inflate.h -- north-star part (5): batched Inflate, one stream per wavefront, decode
+// tables resident in LDS.
+//
+// Replaces CreateReader (LD:2127-2270), GetHuffmanForDecode (LD:2303-2344),
+// DecodeUntilEndOfBlock (LD:2353-2445), DecompressStoreBlock/FixBlock/DynamicBlock
+// (LD:2450-2615), Inflate (LD:2620-2644) and the framing checks of
+// DecompressDeflateInternal / DecompressZlibInternal (LD:2648-2727).
+//
+// Reader model: the reference refills 4 bytes at a time and returns zero bits past the
+// end of input; ReaderBitlenLeft() = 8*len - bits consumed, whatever the refill pattern.
+// The kernel keeps `consumed` and reproduces the same late exhaustion checks (Q11).
+// The bit-serial state is wave-uniform; lanes cooperate on table construction and on
+// match copies.
+#pragma once
+#include "ldh_common.h"
+
+namespace ldh {
+
+constexpr int kLutBits = 10;
+constexpr int kLutSize = 1 << kLutBits;
+
+struct DecTab {
+  uint16_t lut[kLutSize];  // (sym << 4) | len for codes of <= lut_bits bits; 0 = slow path
+  uint16_t symbols[288];   // puff order: by (length, symbol)
+  uint32_t counts[16];
+  uint32_t offs[16];
+  uint32_t first[16];      // first canonical code of each length
+  uint32_t running[16];
+};
+
+struct InflateArgs {
+  const uint8_t *in;
+  const uint64_t *in_off;
+  uint32_t count;
+  int fmt;
+  const uint8_t *dict;
+  uint32_t dlen;
+  uint32_t dict_adler;
+  uint8_t *out;
+  uint64_t out_stride;
+  uint32_t *out_len;
+  uint32_t *bytes_left;
+  int32_t *status;
+  uint32_t *expect_adler;  // zlib trailer value per stream (checked by k_zlib_check)
+};
+
+struct BitReader {
+  const uint32_t *base;  // 4-byte aligned pointer at or before the stream's first byte
+  uint32_t skip;         // bytes between base and the first byte
+  uint32_t nbytes;       // stream length
+  uint32_t chunk;        // per lane: word chunk_w0 + lane
+  uint32_t chunk_w0;     // uniform: first word index held in `chunk`
+  uint32_t next_w;       // uniform: next word to append to bitbuf
+  uint64_t bitbuf;       // uniform
+  uint32_t bitcnt;       // uniform: valid bits in bitbuf
+  uint64_t consumed;     // uniform: bits consumed from the stream so far
+};
+
+__device__ inline void br_load_chunk(BitReader &R, uint32_t w0, uint32_t lane) {
+  const uint32_t w = w0 + lane;
+  const uint64_t first = (uint64_t)w * 4;            // byte offset from base
+  const uint64_t end = (uint64_t)R.skip + R.nbytes;  // one past the last valid byte
+  uint32_t x = 0;
+  if (first < end) {
+    x = R.base[w];
+    if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
+  }
+  R.chunk = x;
+  R.chunk_w0 = w0;
+}
+__device__ inline void br_refill(BitReader &R, uint32_t lane) {
+  while (R.bitcnt <= 32) {
+    if (R.next_w - R.chunk_w0 >= 64) br_load_chunk(R, R.next_w, lane);
+    const uint32_t idx = __builtin_amdgcn_readfirstlane(R.next_w - R.chunk_w0);
+    const uint32_t word = __builtin_amdgcn_readlane(R.chunk, idx);
+    R.bitbuf |= (uint64_t)word << R.bitcnt;
+    R.bitcnt += 32;
+    R.next_w++;
+  }
+}
+// position the reader at stream byte `byte_pos`
+__device__ inline void br_seek(BitReader &R, uint64_t byte_pos, uint32_t lane) {
+  const uint64_t abs = (uint64_t)R.skip + byte_pos;
+  R.consumed = byte_pos * 8;
+  R.next_w = (uint32_t)(abs >> 2);
+  R.bitbuf = 0;
+  R.bitcnt = 0;
+  br_load_chunk(R, R.next_w, lane);
+  br_refill(R, lane);
+  const uint32_t drop = 8 * (uint32_t)(abs & 3);
+  R.bitbuf >>= drop;
+  R.bitcnt -= drop;
+}
+__device__ inline void br_init(BitReader &R, const uint8_t *p, uint32_t n, uint32_t lane) {
+  const uintptr_t a = (uintptr_t)p;
+  R.base = (const uint32_t *)(a & ~(uintptr_t)3);
+  R.skip = (uint32_t)(a & 3);
+  R.nbytes = n;
+  br_seek(R, 0, lane);
+}
+// ReadBits (LD:2140-2161); n <= 16
+__device__ inline uint32_t br_read(BitReader &R, uint32_t n, uint32_t lane) {
+  br_refill(R, lane);
+  const uint32_t v = (uint32_t)(R.bitbuf & ((1ull << n) - 1ull));
+  R.bitbuf >>= n;
+  R.bitcnt -= n;
+  R.consumed += n;
+  return v;
+}
+__device__ inline int64_t br_left(const BitReader &R) {  // ReaderBitlenLeft (LD:2258-2260)
+  return (int64_t)R.nbytes * 8 - (int64_t)R.consumed;
+}
+__device__ inline void br_align(BitReader &R, uint32_t lane) {  // SkipToByteBoundary (LD:2262-2267)
+  const uint32_t s = (uint32_t)((8 - (R.consumed & 7)) & 7);
+  br_refill(R, lane);
+  R.bitbuf >>= s;
+  R.bitcnt -= s;
+  R.consumed += s;
+}
+
+// GetHuffmanForDecode (LD:2303-2344) over lens[0..nsym) (LDS).  Returns `left`:
+// 0 complete (also when there is no code at all, LD:2312-2314), > 0 incomplete,
+// < 0 over-subscribed.  Called by the whole wavefront (block = one wavefront).
+__device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bitlen, int lut_bits,
+                           uint32_t lane) {
+  if (lane < 16) {
+    T.counts[lane] = 0;
+    T.running[lane] = 0;
+    T.offs[lane] = 0;
+    T.first[lane] = 0;
+  }
+  for (int i = lane; i < kLutSize; i += kWave) T.lut[i] = 0;
+  __syncthreads();
+  for (int base = 0; base < nsym; base += kWave) {
+    const int i = base + (int)lane;
+    if (i < nsym) atomicAdd(&T.counts[lens[i]], 1u);
+  }
+  __syncthreads();
+  if (T.counts[0] == (uint32_t)nsym) return 0;  // no codes: "complete", every decode fails
+  int left = 1;
+  for (int len = 1; len <= max_bitlen; len++) {
+    left = left * 2 - (int)T.counts[len];
+    if (left < 0) return left;
+  }
+  if (lane == 0) {
+    uint32_t off = 0, code = 0;
+    for (int len = 1; len <= 15; len++) {
+      code = (code + (len > 1 ? T.counts[len - 1] : 0u)) << 1;
+      T.first[len] = code;
+      T.offs[len] = off;
+      off += T.counts[len];
+    }
+  }
+  __syncthreads();
+  for (int base = 0; base < nsym; base += kWave) {
+    const int i = base + (int)lane;
+    const uint32_t l = i < nsym ? lens[i] : 0;
+    const bool active = l != 0;
+    unsigned long long mask = __ballot(active);
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+      const unsigned long long bal = __ballot(active && ((l >> bit) & 1));
+      mask &= ((l >> bit) & 1) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (active) {
+      const uint32_t in_len = T.running[l] + rank;
+      T.symbols[T.offs[l] + in_len] = (uint16_t)i;
+      if ((int)l <= lut_bits) {
+        const uint32_t c = T.first[l] + in_len;
+        const uint32_t r = __brev(c) >> (32 - l);
+        for (uint32_t k = r; k < (1u << lut_bits); k += (1u << l)) T.lut[k] = (uint16_t)((i << 4) | l);
+      }
+    }
+    __syncthreads();
+    if (active && rank == 0) T.running[l] += (uint32_t)__popcll(mask);
+    __syncthreads();
+  }
+  return left;
+}
+
+// Decode (LD:2206-2256).  Returns the symbol or -10; consumes its bits.
+__device__ inline int decode_sym(const DecTab &T, int lut_bits, BitReader &R, uint32_t lane) {
+  br_refill(R, lane);
+  const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.lut[R.bitbuf & ((1u << lut_bits) - 1u)]);
+  int sym;
+  uint32_t len;
+  if (e) {
+    sym = (int)(e >> 4);
+    len = e & 15;
+  } else {  // canonical bit-serial walk (puff), also the path of every invalid code
+    uint64_t bits = R.bitbuf;
+    int code = 0, first = 0, index = 0;
+    sym = -10;
+    len = 15;
+    for (int l = 1; l <= 15; l++) {
+      code |= (int)(bits & 1);
+      bits >>= 1;
+      const int count = (int)__builtin_amdgcn_readfirstlane(T.counts[l]);
+      if (code - first < count) {
+        sym = (int)__builtin_amdgcn_readfirstlane((uint32_t)T.symbols[index + (code - first)]);
+        len = (uint32_t)l;
+        break;
+      }
+      index += count;
+      first += count;
+      first <<= 1;
+      code <<= 1;
+    }
+  }
+  R.bitbuf >>= len;
+  R.bitcnt -= len;
+  R.consumed += len;
+  return sym;
+}
+
+struct OutState {
+  uint8_t *out;
+  uint64_t cap;
+  uint64_t opos;     // bytes produced
+  uint32_t bufsz;    // the reference's buffer_size (LD:2432-2439): opos minus flushed 32 KiB pages
+  const uint8_t *dict;
+  uint32_t dlen;
+  bool dict_loaded;  // buffer[0] ~= nil (LD:2367)
+};
+
+// DecodeUntilEndOfBlock (LD:2353-2445)
+__device__ int decode_block(const DecTab &LT, const DecTab &DT, int lbits, int dbits, BitReader &R,
+                            OutState &O, uint32_t lane) {
+  uint32_t ext = 0;
+  if (O.dict && !O.dict_loaded) {  // LD:2367-2377
+    ext = O.dlen;
+    O.dict_loaded = true;
+  }
+  for (;;) {
+    const int symbol = decode_sym(LT, lbits, R, lane);
+    if (symbol < 0 || symbol > 285) return -10;
+    if (symbol < 256) {
+      if (O.opos >= O.cap) return kStatusOutputFull;
+      if (lane == 0) O.out[O.opos] = (uint8_t)symbol;
+      O.opos++;
+      O.bufsz++;
+    } else if (symbol > 256) {
+      const uint32_t ls = (uint32_t)symbol - 257;
+      uint32_t len;  // LD:188-200 base lengths, computed instead of tabulated
+      if (ls < 8) {
+        len = 3 + ls;
+      } else if (ls == 28) {
+        len = 258;
+      } else {
+        const uint32_t eb = (ls >> 2) - 1;
+        len = 3 + ((4u + (ls & 3)) << eb) + br_read(R, eb, lane);
+      }
+      const int dsym = decode_sym(DT, dbits, R, lane);
+      if (dsym < 0 || dsym > 29) return -10;
+      uint32_t dist;
+      if (dsym < 4) {
+        dist = (uint32_t)dsym + 1;
+      } else {
+        const uint32_t eb = dist_extra_bits((uint32_t)dsym);
+        dist = 1 + ((2u + ((uint32_t)dsym & 1)) << eb) + br_read(R, eb, lane);
+      }
+      if ((uint64_t)dist > (uint64_t)O.bufsz + ext) return -11;  // LD:2406-2410
+      if (O.opos + len > O.cap) return kStatusOutputFull;
+      // bytes this wave stored earlier must be visible to the loads below
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int64_t src0 = (int64_t)O.opos - (int64_t)dist;
+      for (uint32_t k = lane; k < len; k += kWave) {
+        const uint32_t j = dist >= len ? k : (k % dist);
+        const int64_t si = src0 + j;
+        const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+        O.out[O.opos + k] = byte;
+      }
+      O.opos += len;
+      O.bufsz += len;
+    }
+    if (br_left(R) < 0) return 2;               // LD:2428
+    if (O.bufsz >= 65536) O.bufsz -= 32768;     // LD:2432-2439
+    if (symbol == 256) return 0;
+  }
+}
+
+__global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
+  __shared__ DecTab LT, DT;
+  __shared__ uint8_t lens[320 + 32];
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  const uint64_t off = A.in_off[s];
+  const uint32_t n = (uint32_t)(A.in_off[s + 1] - off);
+  BitReader R;
+  br_init(R, A.in + off, n, lane);
+  OutState O;
+  O.out = A.out + (size_t)s * A.out_stride;
+  O.cap = A.out_stride;
+  O.opos = 0;
+  O.bufsz = 0;
+  O.dict = A.dict;
+  O.dlen = A.dlen;
+  O.dict_loaded = false;
+
+  int status = 0;
+  uint32_t expect = 0;
+  int fixed_ready = 0;
+  do {
+    if (A.fmt == 1) {  // LD:2664-2704
+      const uint32_t cmf = br_read(R, 8, lane);
+      if (br_left(R) < 0) { status = 2; break; }
+      if ((cmf & 15) != 8) { status = -12; break; }
+      if ((cmf >> 4) > 7) { status = -13; break; }
+      const uint32_t flg = br_read(R, 8, lane);
+      if (br_left(R) < 0) { status = 2; break; }
+      if ((cmf * 256 + flg) % 31 != 0) { status = -14; break; }
+      if ((flg >> 5) & 1) {
+        if (!A.dict) { status = -16; break; }
+        uint32_t ad = 0;
+        for (int k = 0; k < 4; k++) ad = (ad << 8) | br_read(R, 8, lane);
+        if (br_left(R) < 0) { status = 2; break; }
+        if (ad != A.dict_adler) { status = -17; break; }
+      }
+    }
+    bool last = false;
+    while (!last && status == 0) {  // LD:2620-2638
+      last = br_read(R, 1, lane) == 1;
+      const uint32_t type = br_read(R, 2, lane);
+      if (type == 0) {  // LD:2450-2491
+        br_align(R, lane);
+        const uint32_t len = br_read(R, 16, lane);
+        if (br_left(R) < 0) { status = 2; break; }
+        const uint32_t comp = br_read(R, 16, lane);
+        if (br_left(R) < 0) { status = 2; break; }
+        if ((len & 255) + (comp & 255) != 255 || (len >> 8) + (comp >> 8) != 255) { status = -2; break; }
+        if (br_left(R) < (int64_t)len * 8) { status = 2; break; }  // ReadBytes: out of input
+        if (O.opos + len > O.cap) { status = kStatusOutputFull; break; }
+        const uint64_t ipos = R.consumed >> 3;
+        const uint8_t *src = A.in + off + ipos;
+        for (uint32_t k = lane; k < len; k += kWave) O.out[O.opos + k] = src[k];
+        O.opos += len;
+        O.bufsz += len;
+        br_seek(R, ipos + len, lane);
+        if (O.bufsz >= 65536) O.bufsz -= 32768;  // LD:2483-2488
+      } else if (type == 1) {  // LD:2496-2501
+        if (fixed_ready != 1) {
+          for (int i = lane; i < 288; i += kWave) lens[i] = (uint8_t)fixed_lit_bits(i);
+          if (lane < 32) lens[288 + lane] = 5;
+          __syncthreads();
+          build_table(LT, lens, 288, 9, kLutBits, lane);
+          build_table(DT, lens + 288, 32, 5, kLutBits, lane);
+          fixed_ready = 1;
+        }
+        status = decode_block(LT, DT, kLutBits, kLutBits, R, O, lane);
+      } else if (type == 2) {  // LD:2506-2615
+        fixed_ready = 0;
+        const uint32_t nlen = br_read(R, 5, lane) + 257;
+        const uint32_t ndist = br_read(R, 5, lane) + 1;
+        const uint32_t ncode = br_read(R, 4, lane) + 4;
+        if (nlen > 286 || ndist > 30) { status = -3; break; }
+        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        __syncthreads();
+        if (lane < 19) lens[lane] = 0;
+        __syncthreads();
+        for (uint32_t i = 0; i < ncode; i++) {
+          const uint32_t v = br_read(R, 3, lane);
+          if (lane == 0) lens[order[i]] = (uint8_t)v;
+        }
+        __syncthreads();
+        if (build_table(DT, lens, 19, 7, 7, lane) != 0) { status = -4; break; }
+        __syncthreads();
+        for (int i = lane; i < 320; i += kWave) lens[i] = 0;
+        __syncthreads();
+        uint32_t index = 0;
+        uint32_t prev_len = 0;  // lens[index-1], tracked in a register
+        while (index < nlen + ndist) {
+          int symbol = decode_sym(DT, 7, R, lane);
+          if (symbol < 0) { status = symbol; break; }
+          if (symbol < 16) {
+            if (lane == 0) lens[index] = (uint8_t)symbol;
+            prev_len = (uint32_t)symbol;
+            index++;
+          } else {
+            uint32_t bitlen = 0, rep;
+            if (symbol == 16) {
+              if (index == 0) { status = -5; break; }
+              bitlen = prev_len;
+              rep = 3 + br_read(R, 2, lane);
+            } else if (symbol == 17) {
+              rep = 3 + br_read(R, 3, lane);
+            } else {
+              rep = 11 + br_read(R, 7, lane);
+            }
+            if (index + rep > nlen + ndist) { status = -6; break; }
+            for (uint32_t k = lane; k < rep; k += kWave) lens[index + k] = (uint8_t)bitlen;
+            prev_len = bitlen;
+            index += rep;
+          }
+        }
+        if (status != 0) break;
+        __syncthreads();
+        if (lens[256] == 0) { status = -9; break; }
+        // the distance lengths follow the nlen literal/length lengths; move them apart
+        const uint8_t dl = lane < ndist ? lens[nlen + lane] : 0;
+        __syncthreads();
+        if (lane < 32) lens[320 + lane] = dl;
+        __syncthreads();
+        int err = build_table(LT, lens, (int)nlen, 15, kLutBits, lane);
+        if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
+        err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
+        if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
+        status = decode_block(LT, DT, kLutBits, kLutBits, R, O, lane);
+      } else {
+        status = -1;
+      }
+    }
+    if (status != 0) break;
+    if (A.fmt == 1) {  // LD:2707-2722 (the Adler comparison itself is k_zlib_check)
+      br_align(R, lane);
+      for (int k = 0; k < 4; k++) expect = (expect << 8) | br_read(R, 8, lane);
+      if (br_left(R) < 0) { status = 2; break; }
+    }
+  } while (false);
+
+  if (lane == 0) {
+    const int64_t left = br_left(R);
+    A.status[s] = status;
+    A.out_len[s] = (uint32_t)O.opos;
+    A.bytes_left[s] = (status == 0 && left > 0) ? (uint32_t)(left / 8) : 0u;
+    if (A.expect_adler) A.expect_adler[s] = expect;
+  }
+}
+
+// DecompressZlibInternal's final comparison (LD:2717-2722)
+__global__ void k_zlib_check(uint32_t count, const uint32_t *expect, const uint32_t *actual,
+                             int32_t *status) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= count) return;
+  if (status[s] == 0 && expect[s] != actual[s]) status[s] = -15;
+}
+
+}  // namespace ldh

@@ -1,0 +1,386 @@
+// k_lz77.h -- north-star part (1): trigram chains, longest-match search, parse.
+//
+// Replaces GetBlockLZ77Result (LD:1241-1484) + LoadStringToTable (LD:1184-1197) and the
+// dictionary chains of CreateDictionary (LD:531-595).
+//
+//   k_sort_links   one workgroup per stream: materialise V = dict ++ input, stable LSD
+//                  radix sort of all positions by their exact trigram (Q1: the "hash" is
+//                  the three bytes themselves), then prevd[v] = distance to the previous
+//                  position with the same trigram (0 = none within 32768).
+//   k_match_lazy   levels 4-9.  Every position is inserted (Q4) and depth is always
+//                  max_chain (Q3), so the best match at a position does not depend on
+//                  the parse: one lane per position, window bytes + links staged in LDS.
+//   k_parse_lazy   the lazy state machine of LD:1318-1476 (Q5), one lane per deflate block.
+//   k_lz_greedy    levels 1-3: insertion depends on the parse (Q4), one lane per stream.
+#pragma once
+#include "ldh_common.h"
+
+namespace ldh {
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range
+// of work items so that tiles of one stream reuse that XCD's L2.  Bijective for any total.
+__device__ inline uint32_t xcd_remap(uint32_t bid, uint32_t total) {
+  uint32_t q = total / 8, r = total % 8, xcd = bid % 8, j = bid / 8;
+  uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}
+
+__device__ inline uint32_t trigram(const uint8_t *V, uint32_t v) {
+  return ((uint32_t)V[v] << 16) | ((uint32_t)V[v + 1] << 8) | (uint32_t)V[v + 2];
+}
+
+// ------------------------------------------------------------------ k_sort_links
+constexpr int kSortThreads = 1024;
+constexpr int kSortWaves = kSortThreads / kWave;
+
+// exclusive scan of 256 values held by threads 0..255 (one value each); result in out[256]
+__device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *out, uint32_t *wave_tot) {
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint32_t inc = val;
+  if (tid < 256) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t t = __shfl_up(inc, off);
+      if (lane >= (uint32_t)off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+    out[tid] = base + inc - val;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_base[256];
+  __shared__ uint32_t s_cnt[kSortWaves][256];
+  __shared__ uint32_t s_off[kSortWaves][256];
+  __shared__ uint32_t s_tot[4];
+
+  const uint32_t s = blockIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n = stream_len(B, s), D = B.dlen, nv = D + n;
+  uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint8_t *in = B.in + B.in_off[s];
+  uint32_t *bufA = B.bufA + (size_t)s * B.nvp;
+  uint32_t *bufB = B.bufB + (size_t)s * B.nvp;
+  uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+
+  if (tid < 256) s_hist[tid] = 0;
+  for (uint32_t i = tid; i < kSortWaves * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
+  __syncthreads();
+
+  // V = dict ++ input ++ zeros, written as dwords (V is 16-byte aligned)
+  const uint32_t total = (nv + kVPad) & ~3u;  // nv + kVPad <= nvp + kVPad
+  for (uint32_t w = tid * 4; w < total; w += kSortThreads * 4) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t i = w + k;
+      uint32_t byte = 0;
+      if (i < nv) {
+        byte = i < D ? B.dict[i] : in[i - D];
+        atomicAdd(&s_hist[byte], 1u);
+      }
+      word |= byte << (8 * k);
+    }
+    *(uint32_t *)(V + w) = word;
+  }
+  __syncthreads();
+  if (nv == 0) return;
+
+  for (int pass = 0; pass < 3; pass++) {
+    const uint32_t shift = 2 - pass;  // digit of v is V[v + shift]
+    const uint32_t *src = pass == 1 ? bufA : bufB;
+    uint32_t *dst = pass == 1 ? bufB : bufA;
+    {  // bin bases: histogram of V[shift .. shift+nv-1] (zero padded), exclusive scan
+      uint32_t cnt = 0;
+      if (tid < 256) {
+        const uint32_t m = shift < nv ? shift : nv;
+        cnt = s_hist[tid];
+        for (uint32_t j = 0; j < m; j++) cnt -= ((uint32_t)V[j] == tid);
+        if (tid == 0) cnt += m;
+      }
+      scan256_exclusive(cnt, tid, s_base, s_tot);
+    }
+
+    const uint32_t ntiles = (nv + kSortThreads - 1) / kSortThreads;
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+      const uint32_t idx = tile * kSortThreads + tid;
+      const bool valid = idx < nv;
+      uint32_t e = 0, d = 0;
+      if (valid) {
+        e = pass == 0 ? idx : src[idx];
+        d = V[e + shift];
+      }
+      // lanes of this wave holding the same digit (stable rank = lanes below me)
+      unsigned long long mask = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        unsigned long long bal = __ballot(valid && ((d >> bit) & 1));
+        mask &= ((d >> bit) & 1) ? bal : ~bal;
+      }
+      const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+      if (valid && rank == 0) s_cnt[wave][d] = __popcll(mask);
+      __syncthreads();
+      if (tid < 256) {  // per digit: running offsets over the waves; leaves s_cnt zeroed
+        uint32_t off = s_base[tid];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; w++) {
+          uint32_t t = s_cnt[w][tid];
+          s_cnt[w][tid] = 0;
+          s_off[w][tid] = off;
+          off += t;
+        }
+        s_base[tid] = off;
+      }
+      __syncthreads();
+      if (valid) dst[s_off[wave][d] + rank] = e;
+      // next tile: s_cnt writes do not alias s_off; the barrier after them orders the
+      // s_off reads above before the next rewrite of s_off.
+    }
+    __syncthreads();
+  }
+
+  // links: neighbours in sorted order that share the trigram
+  for (uint32_t r = tid; r < nv; r += kSortThreads) {
+    uint32_t v = bufA[r];
+    uint32_t dlt = 0;
+    if (r > 0) {
+      uint32_t u = bufA[r - 1];
+      if (trigram(V, u) == trigram(V, v)) {
+        uint32_t d = v - u;
+        if (d <= kWindow) dlt = d;
+      }
+    }
+    prevd[v] = (uint16_t)dlt;
+  }
+}
+
+// ------------------------------------------------------------------ k_match_lazy
+constexpr uint32_t kTile = 4096;
+constexpr int kMatchThreads = 1024;
+constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
+constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
+constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
+
+__device__ inline uint32_t lds_load4(const uint32_t *w, uint32_t byteoff) {
+  uint32_t i = byteoff >> 2;
+  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
+}
+
+__global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t tiles_per_stream) {
+  extern __shared__ uint32_t smem[];
+  uint32_t *lbytes = smem;                                       // kLdsByteCap bytes
+  uint16_t *lprev = (uint16_t *)(smem + kLdsByteCap / 4);        // kLdsPrevCap entries
+
+  const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t s = work / tiles_per_stream, tile = work % tiles_per_stream;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = stream_len(B, s), D = B.dlen;
+  const uint32_t q0 = tile * kTile;
+  if (q0 >= n) return;
+  const uint32_t q1 = (q0 + kTile < n) ? q0 + kTile : n;  // stream positions [q0, q1) 0-based
+  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+  uint32_t *mout = B.bufB + (size_t)s * B.nvp;
+  const LevelCfg cfg = level_cfg(B.level);
+
+  const uint32_t v0 = q0 + D, v1 = q1 + D;
+  const uint32_t wbase = (v0 > kWindow ? v0 - kWindow : 0) & ~3u;
+  {  // stage bytes [wbase, v1 + 280) (zero beyond the allocated pad) and links [wbase, v1)
+    const uint32_t alloc_end = D + n + kVPad;  // bytes valid in vbuf
+    const uint32_t nb = (v1 + 280 - wbase + 3) / 4;
+    const uint32_t *gsrc = (const uint32_t *)(V + wbase);
+    for (uint32_t i = tid; i < nb; i += kMatchThreads)
+      lbytes[i] = (wbase + 4 * i + 4 <= alloc_end) ? gsrc[i] : 0u;
+    const uint32_t np = (v1 - wbase + 1) / 2;
+    const uint32_t *psrc = (const uint32_t *)(prevd + wbase);
+    uint32_t *pdst = (uint32_t *)lprev;
+    for (uint32_t i = tid; i < np; i += kMatchThreads) pdst[i] = psrc[i];
+  }
+  __syncthreads();
+
+  for (uint32_t q = q0 + tid; q < q1; q += kMatchThreads) {
+    const uint32_t p = q + 1;
+    const uint32_t blk = p <= kFirstBlock ? 0u : 1u + (p - kFirstBlock - 1) / kNextBlock;
+    const uint32_t be = block_end(blk, n);
+    uint32_t best = 0, bdist = 0;
+    if (p + 2 <= be) {  // LD:1349
+      const uint32_t v = q + D;
+      uint32_t maxlen = be - p + 1;
+      if (maxlen > kMaxMatch) maxlen = kMaxMatch;
+      const uint32_t t0w = lds_load4(lbytes, v + 3 - wbase);
+      const uint32_t t1w = lds_load4(lbytes, v + 7 - wbase);
+      uint32_t c = v;
+      int depth = cfg.max_chain;  // Q3
+      bool seen_seed = false;
+      while (depth > 0) {
+        const uint32_t d = lprev[c - wbase];
+        if (d == 0) break;
+        c -= d;
+        if (v - c > kWindow) break;  // LD:1365
+        if (c < D) {                 // dictionary side of V (Q10)
+          if (c + 2 < D) {           // LibDeflate position <= -2: dictionary chain entry
+            if (seen_seed) break;    // LD:1394: no fall-through after a seed (-1 / 0)
+          } else {
+            seen_seed = true;
+          }
+        }
+        uint32_t L;
+        uint32_t x = lds_load4(lbytes, c + 3 - wbase) ^ t0w;
+        if (x) {
+          L = 3 + (__builtin_ctz(x) >> 3);
+        } else {
+          x = lds_load4(lbytes, c + 7 - wbase) ^ t1w;
+          if (x) {
+            L = 7 + (__builtin_ctz(x) >> 3);
+          } else {
+            L = 11;
+            while (L < maxlen) {
+              x = lds_load4(lbytes, c + L - wbase) ^ lds_load4(lbytes, v + L - wbase);
+              if (x) {
+                L += __builtin_ctz(x) >> 3;
+                break;
+              }
+              L += 4;
+            }
+          }
+        }
+        if (L > maxlen) L = maxlen;
+        if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
+          best = L;
+          bdist = v - c;
+        }
+        if (best >= (uint32_t)cfg.nice) break;  // LD:1389
+        depth--;
+      }
+    }
+    mout[q] = best ? ((best << 16) | bdist) : 0u;
+  }
+}
+
+// ------------------------------------------------------------------ k_parse_lazy
+// LD:1318-1476, lazy branch.  One lane per (stream, block); parse state is reset per
+// block (Q6).  Reads the per-position best match, writes tokens.
+__global__ void k_parse_lazy(Batch B) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t s = gid / B.max_blocks, b = gid % B.max_blocks;
+  if (s >= B.count) return;
+  const uint32_t n = stream_len(B, s);
+  if (b >= num_blocks(n)) return;
+  const uint32_t bs = block_start(b), be = block_end(b, n);
+  const uint32_t D = B.dlen;
+  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint32_t *m = B.bufB + (size_t)s * B.nvp;
+  uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
+  const LevelCfg cfg = level_cfg(B.level);
+
+  uint32_t i = bs, ntok = 0;
+  bool avail = false;
+  uint32_t cur_len = 0, cur_dist = 0;
+  while (i <= be + 1) {
+    const uint32_t prev_len = cur_len, prev_dist = cur_dist;
+    cur_len = 0;
+    if (i <= be && prev_len < (uint32_t)cfg.max_lazy) {  // LD:1349-1350
+      const uint32_t mm = m[i - 1];
+      cur_len = mm >> 16;
+      if (cur_len) cur_dist = mm & 0xFFFF;
+    }
+    if (avail && (prev_len > 3 || (prev_len == 3 && prev_dist < 4096)) && cur_len <= prev_len) {
+      tok[ntok++] = tok_match(prev_len, prev_dist);  // match for position i-1
+      i += prev_len - 1;
+      avail = false;
+    } else if (avail) {
+      tok[ntok++] = V[D + i - 2];  // literal at position i-1
+      i++;
+    } else {
+      avail = true;
+      i++;
+    }
+  }
+  B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
+}
+
+// ------------------------------------------------------------------ k_lz_greedy
+// Levels 1-3 (LD:1318-1476, non-lazy branch).  Positions inside a match longer than
+// max_insert_length are not inserted (Q4), so the candidate set depends on the parse:
+// one lane walks one stream.  flags[q] = 1 once stream position q is in a chain
+// (bufB must be zeroed by the caller).
+__global__ void k_lz_greedy(Batch B) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.count) return;
+  const uint32_t n = stream_len(B, s), D = B.dlen;
+  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+  uint8_t *flags = (uint8_t *)(B.bufB + (size_t)s * B.nvp);
+  const LevelCfg cfg = level_cfg(B.level);
+  const uint32_t nblk = num_blocks(n);
+
+  for (uint32_t b = 0; b < nblk; b++) {
+    const uint32_t bs = block_start(b), be = block_end(b, n);
+    uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
+    uint32_t ntok = 0, i = bs;
+    while (i <= be) {
+      const uint32_t v = i - 1 + D;
+      flags[i - 1] = 1;  // LD:1347
+      uint32_t cur_len = 0, cur_dist = 0;
+      if (i + 2 <= be) {
+        uint32_t maxlen = be - i + 1;
+        if (maxlen > kMaxMatch) maxlen = kMaxMatch;
+        uint32_t c = v;
+        int depth = cfg.max_chain;
+        bool seen_seed = false;
+        while (depth > 0) {
+          const uint32_t d = prevd[c];
+          if (d == 0) break;
+          c -= d;
+          if (v - c > kWindow) break;
+          if (c >= D) {
+            if (!flags[c - D]) continue;  // never inserted: not in the reference's chain
+          } else if (c + 2 < D) {
+            if (seen_seed) break;
+          } else {
+            seen_seed = true;
+          }
+          uint32_t L = 3;
+          while (L < maxlen && V[c + L] == V[v + L]) L++;
+          if (L > cur_len) {
+            cur_len = L;
+            cur_dist = v - c;
+          }
+          if (cur_len >= (uint32_t)cfg.nice) break;
+          depth--;
+        }
+      }
+      if (cur_len > 3 || (cur_len == 3 && cur_dist < 4096)) {
+        tok[ntok++] = tok_match(cur_len, cur_dist);
+        if (cur_len <= (uint32_t)cfg.max_lazy)  // max_insert_length, LD:1249,1454
+          for (uint32_t j = i + 1; j <= i + cur_len - 1; j++) flags[j - 1] = 1;
+        i += cur_len;
+      } else {
+        tok[ntok++] = V[v];
+        i++;
+      }
+    }
+    B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
+  }
+}
+
+// strategy "huffman_only" (LD:1833-1845): every byte is a literal token.
+__global__ void k_tokens_literal(Batch B) {
+  const uint32_t s = blockIdx.x;
+  const uint32_t n = stream_len(B, s), D = B.dlen;
+  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  uint32_t *tok = B.bufA + (size_t)s * B.nvp;
+  for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) tok[q] = V[D + q];
+  const uint32_t nblk = num_blocks(n);
+  for (uint32_t b = threadIdx.x; b < nblk; b += blockDim.x)
+    B.blocks[(size_t)s * B.max_blocks + b].ntok = n ? block_end(b, n) - block_start(b) + 1 : 0;
+}
+
+}  // namespace ldh

@@ -1,0 +1,784 @@
+// ldh_api.hip -- host side of libdeflate_hip.so: the C ABI of include/libdeflate_hip.h
+// over the gfx950 kernels.  No CPU fallback exists: every entry point needs a HIP device.
+#include "../../include/libdeflate_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "k_huffman.h"
+#include "k_inflate.h"
+#include "k_lz77.h"
+#include "k_misc.h"
+#include "ldh_common.h"
+
+using namespace ldh;
+
+struct ldh_dict {
+  uint8_t *d_bytes;
+  size_t n;
+  uint32_t adler;
+};
+
+namespace {
+
+std::mutex g_mu;
+thread_local std::string g_err;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+// workspace (grow-only)
+DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_blocks, g_adler, g_misc32a, g_misc32b;
+// staging for the host-pointer entry points
+DevBuf g_h_in, g_h_off, g_h_out, g_h_len, g_h_aux8, g_h_aux32a, g_h_aux32b;
+
+// last compress batch (for ldh_debug_fetch)
+Batch g_last{};
+bool g_have_last = false;
+
+// profiler
+bool g_prof = false;
+struct ProfEntry {
+  std::string name;
+  double ms = 0;
+  uint64_t launches = 0;
+};
+std::vector<ProfEntry> g_prof_entries;
+struct Pending {
+  int idx;
+  hipEvent_t a, b;
+};
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(LDH_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    hipStreamSynchronize(g_stream);
+    hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes + 4096;
+    e = hipMalloc(&b.p, want);
+  }
+  if (e != hipSuccess) return fail(LDH_E_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+  b.cap = want;
+  return 0;
+}
+
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+int prof_index(const char *name) {
+  for (size_t i = 0; i < g_prof_entries.size(); i++)
+    if (g_prof_entries[i].name == name) return (int)i;
+  g_prof_entries.push_back({name, 0, 0});
+  return (int)g_prof_entries.size() - 1;
+}
+void prof_drain() {
+  if (g_pending.empty()) return;
+  hipStreamSynchronize(g_stream);
+  for (auto &p : g_pending) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    g_prof_entries[p.idx].ms += ms;
+    g_prof_entries[p.idx].launches++;
+    g_event_pool.push_back(p.a);
+    g_event_pool.push_back(p.b);
+  }
+  g_pending.clear();
+}
+
+struct ProfScope {
+  int idx = -1;
+  hipEvent_t a = nullptr;
+  explicit ProfScope(const char *name) {
+    if (g_prof) {
+      idx = prof_index(name);
+      a = get_event();
+      hipEventRecord(a, g_stream);
+    }
+  }
+  ~ProfScope() {
+    if (idx >= 0) {
+      hipEvent_t b = get_event();
+      hipEventRecord(b, g_stream);
+      g_pending.push_back({idx, a, b});
+      if (g_pending.size() > 4096) prof_drain();
+    }
+  }
+};
+
+#define LAUNCH(name, kern, grid, block, shmem, ...)                                   \
+  do {                                                                                \
+    ProfScope ps_(name);                                                              \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, g_stream, __VA_ARGS__); \
+  } while (0)
+
+size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+size_t workspace_budget() {
+  const char *e = getenv("LDH_WORKSPACE_MB");
+  size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 32768;
+  if (mb < 64) mb = 64;
+  return mb << 20;
+}
+
+bool g_attr_done = false;
+
+int check_init() {
+  if (g_device < 0) return fail(LDH_E_NOT_INIT, "ldh_init() has not been called");
+  return 0;
+}
+
+// ---- compress ---------------------------------------------------------------
+int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
+                        int fmt, int level, int strategy, const ldh_dict *dict, uint8_t *d_out,
+                        size_t out_stride, uint32_t *d_out_len, uint8_t *d_pad_bits) {
+  if (int rc = check_init()) return rc;
+  if (count == 0) return 0;
+  if (level < 0 || level > 9) return fail(LDH_E_ARG, "level must be 0..9 for *_dev (got %d)", level);
+  if (strategy < 0 || strategy > 3) return fail(LDH_E_ARG, "bad strategy %d", strategy);
+  if (fmt != 0 && fmt != 1) return fail(LDH_E_ARG, "bad fmt %d", fmt);
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  if (max_in_len > 0xFFFF0000ull) return fail(LDH_E_ARG, "streams of 4 GiB or more are not supported");
+  if (out_stride < ldh_compress_bound(max_in_len))
+    return fail(LDH_E_CAPACITY, "out_stride %zu < ldh_compress_bound(%zu) = %zu", out_stride, max_in_len,
+                ldh_compress_bound(max_in_len));
+  const uint32_t dlen = dict ? (uint32_t)dict->n : 0;
+  const bool need_lz = level != 0 && strategy != LDH_STRATEGY_HUFFMAN_ONLY;
+  // the dictionary only matters to the match search; keep V = input otherwise
+  const uint32_t vd = need_lz ? dlen : 0;
+  const uint32_t nvp = (uint32_t)round_up((size_t)vd + max_in_len + 16, 16);
+  const uint32_t max_blocks = num_blocks((uint32_t)max_in_len);
+
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + 8ull * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
+  size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
+  if (chunk > count) chunk = count;
+
+  if (int rc = ensure(g_vbuf, chunk * (size_t)(nvp + kVPad) + 64)) return rc;
+  if (int rc = ensure(g_prevd, chunk * 2ull * nvp + 64)) return rc;
+  if (int rc = ensure(g_bufA, chunk * 4ull * nvp + 64)) return rc;
+  if (int rc = ensure(g_bufB, chunk * 4ull * nvp + 64)) return rc;
+  if (int rc = ensure(g_blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
+  if (int rc = ensure(g_adler, chunk * 4 + 64)) return rc;
+
+  if (!g_attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)kMatchLdsBytes));
+    g_attr_done = true;
+  }
+
+  for (size_t s0 = 0; s0 < count; s0 += chunk) {
+    const uint32_t c = (uint32_t)std::min(chunk, count - s0);
+    Batch B{};
+    B.in = d_in;
+    B.in_off = d_in_off + s0;
+    B.count = c;
+    B.dict = vd ? dict->d_bytes : nullptr;
+    B.dlen = vd;
+    B.dict_adler = dict ? dict->adler : 0;
+    B.max_len = (uint32_t)max_in_len;
+    B.nvp = nvp;
+    B.max_blocks = max_blocks;
+    B.level = level;
+    B.strategy = strategy;
+    B.fmt = fmt;
+    B.vbuf = (uint8_t *)g_vbuf.p;
+    B.prevd = (uint16_t *)g_prevd.p;
+    B.bufA = (uint32_t *)g_bufA.p;
+    B.bufB = (uint32_t *)g_bufB.p;
+    B.blocks = (BlockInfo *)g_blocks.p;
+    B.adler = (uint32_t *)g_adler.p;
+    B.out = d_out + s0 * out_stride;
+    B.out_stride = out_stride;
+    B.out_len = d_out_len + s0;
+    B.pad_bits = d_pad_bits + s0;
+    // k_plan / k_bitpack read the zlib DICTID even when V carries no dictionary
+    Batch Bz = B;
+    Bz.dict = dict ? dict->d_bytes : nullptr;
+
+    // V (and, for the match search, the trigram chains)
+    LAUNCH("k_sort_links", k_sort_links, c, kSortThreads, 0, B);  // TODO(round 2): skip the sort for level 0 / huffman_only
+    if (level != 0) {
+      if (strategy == LDH_STRATEGY_HUFFMAN_ONLY) {
+        LAUNCH("k_tokens_literal", k_tokens_literal, c, 256, 0, B);
+      } else if (level_cfg(level).lazy) {
+        const uint32_t tiles = (uint32_t)((max_in_len + kTile - 1) / kTile);
+        if (tiles) LAUNCH("k_match_lazy", k_match_lazy, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        const uint32_t units = c * max_blocks;
+        LAUNCH("k_parse_lazy", k_parse_lazy, (units + 63) / 64, 64, 0, B);
+      } else {
+        HIPCHK(hipMemsetAsync(B.bufB, 0, (size_t)c * 4ull * nvp, g_stream));
+        LAUNCH("k_lz_greedy", k_lz_greedy, (c + 63) / 64, 64, 0, B);
+      }
+      LAUNCH("k_histogram", k_histogram, c * max_blocks, 256, 0, B);
+      LAUNCH("k_huffman", k_huffman, c * max_blocks, kWave, 0, B);
+    }
+    if (fmt == 1)
+      LAUNCH("k_adler32", k_adler32, c, kAdlerThreads, 0, d_in, B.in_off, (uint64_t)0, (const uint32_t *)nullptr, B.adler);
+    LAUNCH("k_plan", k_plan, (c + 63) / 64, 64, 0, Bz);
+    LAUNCH("k_bitpack", k_bitpack, c * max_blocks, kPackThreads, 0, Bz);
+    HIPCHK(hipGetLastError());
+    g_last = B;
+    g_have_last = true;
+  }
+  return 0;
+}
+
+// ---- decompress -------------------------------------------------------------
+int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, int fmt,
+                          const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
+                          uint32_t *d_bytes_left, int32_t *d_status) {
+  if (int rc = check_init()) return rc;
+  if (count == 0) return 0;
+  if (fmt != 0 && fmt != 1) return fail(LDH_E_ARG, "bad fmt %d", fmt);
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  if (int rc = ensure(g_misc32a, count * 4 + 64)) return rc;
+  if (int rc = ensure(g_misc32b, count * 4 + 64)) return rc;
+  InflateArgs A{};
+  A.in = d_in;
+  A.in_off = d_in_off;
+  A.count = (uint32_t)count;
+  A.fmt = fmt;
+  A.dict = dict ? dict->d_bytes : nullptr;
+  A.dlen = dict ? (uint32_t)dict->n : 0;
+  A.dict_adler = dict ? dict->adler : 0;
+  A.out = d_out;
+  A.out_stride = out_stride;
+  A.out_len = d_out_len;
+  A.bytes_left = d_bytes_left;
+  A.status = d_status;
+  A.expect_adler = (uint32_t *)g_misc32a.p;
+  LAUNCH("k_inflate", k_inflate, (uint32_t)count, kWave, 0, A);
+  if (fmt == 1) {
+    LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)d_out,
+           (const uint64_t *)nullptr, (uint64_t)out_stride, (const uint32_t *)d_out_len, (uint32_t *)g_misc32b.p);
+    LAUNCH("k_zlib_check", k_zlib_check, (uint32_t)((count + 255) / 256), 256, 0, (uint32_t)count,
+           (const uint32_t *)g_misc32a.p, (const uint32_t *)g_misc32b.p, d_status);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// host staging helpers ---------------------------------------------------------
+int upload_inputs(const uint8_t *in_base, const uint64_t *in_off, size_t count) {
+  const uint64_t total = in_off[count];
+  if (int rc = ensure(g_h_in, total + 64)) return rc;
+  if (int rc = ensure(g_h_off, (count + 1) * 8)) return rc;
+  // offsets are re-based to start at 0 so that the device copy of the data is aligned
+  std::vector<uint64_t> off(count + 1);
+  for (size_t i = 0; i <= count; i++) off[i] = in_off[i] - in_off[0];
+  if (total - in_off[0])
+    HIPCHK(hipMemcpyAsync(g_h_in.p, in_base + in_off[0], total - in_off[0], hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(g_h_off.p, off.data(), (count + 1) * 8, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));  // `off` goes out of scope
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int ldh_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_device == device && g_stream) return 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(LDH_E_HIP, "no HIP device: %s", hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(LDH_E_ARG, "device %d out of range (count %d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  if (g_stream && g_device != device) return fail(LDH_E_ARG, "already initialised on device %d", g_device);
+  HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&g_t0));
+  HIPCHK(hipEventCreate(&g_t1));
+  g_device = device;
+  return 0;
+}
+
+void ldh_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_device < 0) return;
+  hipStreamSynchronize(g_stream);
+  for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
+                    &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b}) {
+    if (b->p) hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  g_have_last = false;
+  hipStreamDestroy(g_stream);
+  g_stream = nullptr;
+  g_device = -1;
+}
+
+int ldh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *ldh_last_error(void) { return g_err.c_str(); }
+void *ldh_stream(void) { return (void *)g_stream; }
+int ldh_sync(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+size_t ldh_compress_bound(size_t n) {
+  // forced fixed/dynamic strategies can exceed the stored size (<= ~9.2 bits per literal
+  // plus a dynamic header per block); rounded so it can be used as out_stride.
+  size_t nblocks = n <= kFirstBlock ? 1 : 1 + (n - kFirstBlock + kNextBlock - 1) / kNextBlock;
+  return round_up(n + n / 4 + 512 * nblocks + 64, 16);
+}
+
+ldh_dict *ldh_dict_create(const uint8_t *bytes, size_t n) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (check_init()) return nullptr;
+  if (!bytes || n == 0 || n > 32768) {  // LD:513-521
+    fail(LDH_E_ARG, "dictionary length must be 1..32768 (got %zu)", n);
+    return nullptr;
+  }
+  ldh_dict *d = new ldh_dict{nullptr, n, 0};
+  if (hipMalloc((void **)&d->d_bytes, n + 64) != hipSuccess) {
+    delete d;
+    fail(LDH_E_NOMEM, "hipMalloc dict");
+    return nullptr;
+  }
+  hipMemsetAsync(d->d_bytes, 0, n + 64, g_stream);
+  hipMemcpyAsync(d->d_bytes, bytes, n, hipMemcpyHostToDevice, g_stream);
+  // Adler-32 of the dictionary through the device kernel (LD:522)
+  uint64_t off[2] = {0, n};
+  uint64_t *d_off = nullptr;
+  uint32_t *d_ad = nullptr;
+  hipMalloc((void **)&d_off, 16);
+  hipMalloc((void **)&d_ad, 4);
+  hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, g_stream);
+  hipLaunchKernelGGL(k_adler32, dim3(1), dim3(kAdlerThreads), 0, g_stream, (const uint8_t *)d->d_bytes,
+                     (const uint64_t *)d_off, (uint64_t)0, (const uint32_t *)nullptr, d_ad);
+  hipMemcpyAsync(&d->adler, d_ad, 4, hipMemcpyDeviceToHost, g_stream);
+  hipError_t e = hipStreamSynchronize(g_stream);
+  hipFree(d_off);
+  hipFree(d_ad);
+  if (e != hipSuccess) {
+    hipFree(d->d_bytes);
+    delete d;
+    fail(LDH_E_HIP, "dict upload: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  return d;
+}
+void ldh_dict_free(ldh_dict *d) {
+  if (!d) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_stream) hipStreamSynchronize(g_stream);
+  hipFree(d->d_bytes);
+  delete d;
+}
+uint32_t ldh_dict_adler32(const ldh_dict *d) { return d ? d->adler : 0; }
+size_t ldh_dict_len(const ldh_dict *d) { return d ? d->n : 0; }
+
+// ---- batched, device pointers -------------------------------------------------
+int ldh_compress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
+                           int fmt, int level, int strategy, const ldh_dict *dict, uint8_t *d_out,
+                           size_t out_stride, uint32_t *d_out_len, uint8_t *d_pad_bits) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return compress_dev_locked(d_in, d_in_off, count, max_in_len, fmt, level, strategy, dict, d_out, out_stride,
+                             d_out_len, d_pad_bits);
+}
+
+int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, int fmt,
+                             const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
+                             uint32_t *d_bytes_left, int32_t *d_status) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return decompress_dev_locked(d_in, d_in_off, count, fmt, dict, d_out, out_stride, d_out_len, d_bytes_left,
+                               d_status);
+}
+
+int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint32_t *d_adler) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!count) return 0;
+  LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, d_in, d_in_off, (uint64_t)0,
+         (const uint32_t *)nullptr, d_adler);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ldh_print6_encode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint8_t *d_out,
+                                size_t out_stride, uint32_t *d_out_len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  LAUNCH("k_print6_encode", k_print6_encode, (uint32_t)count, kP6Threads, 0, d_in, d_in_off, d_out,
+         (uint64_t)out_stride, d_out_len);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ldh_print6_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint8_t *d_out,
+                                size_t out_stride, uint32_t *d_out_len, uint8_t *d_ok) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!count) return 0;
+  LAUNCH("k_print6_decode", k_print6_decode, (uint32_t)count, kP6Threads, 0, d_in, d_in_off, d_out,
+         (uint64_t)out_stride, d_out_len, d_ok);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- batched, host pointers ---------------------------------------------------
+int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt, int level,
+                       int strategy, const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
+                       uint32_t *out_len, uint8_t *pad_bits) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (count == 0) return 0;
+  if (level < -1 || level > 9) return fail(LDH_E_ARG, "level must be -1..9 (got %d)", level);
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  // group streams by resolved level (LD:1782-1790) and by size class so that the
+  // per-stream workspace (sized by the longest stream of a launch) is not wasted
+  struct Group {
+    int level;
+    std::vector<size_t> idx;
+    size_t max_len = 0;
+  };
+  std::vector<Group> groups;
+  for (size_t s = 0; s < count; s++) {
+    const size_t n = in_off[s + 1] - in_off[s];
+    int lv = level;
+    if (lv < 0) lv = n < 2048 ? 7 : (n > 65536 ? 3 : 5);
+    int cls = 0;
+    while (((size_t)4096 << cls) < n && cls < 20) cls++;
+    const int key = lv * 32 + cls;
+    Group *g = nullptr;
+    for (auto &gg : groups)
+      if (gg.level == key) g = &gg;
+    if (!g) {
+      groups.push_back({key, {}, 0});
+      g = &groups.back();
+    }
+    g->idx.push_back(s);
+    g->max_len = std::max(g->max_len, n);
+  }
+  for (auto &g : groups) {
+    const size_t gc = g.idx.size();
+    const int lv = g.level / 32;
+    if (out_stride < ldh_compress_bound(g.max_len))
+      return fail(LDH_E_CAPACITY, "out_stride %zu < ldh_compress_bound(%zu)", out_stride, g.max_len);
+    // gather this group's streams contiguously
+    std::vector<uint64_t> off(gc + 1);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < gc; i++) {
+      off[i] = tot;
+      tot += in_off[g.idx[i] + 1] - in_off[g.idx[i]];
+    }
+    off[gc] = tot;
+    const bool contiguous = (g.idx.back() - g.idx.front() + 1 == gc);
+    if (int rc = ensure(g_h_in, tot + 64)) return rc;
+    if (int rc = ensure(g_h_off, (gc + 1) * 8)) return rc;
+    if (int rc = ensure(g_h_out, gc * out_stride)) return rc;
+    if (int rc = ensure(g_h_len, gc * 4 + 64)) return rc;
+    if (int rc = ensure(g_h_aux8, gc + 64)) return rc;
+    if (contiguous) {
+      if (tot) HIPCHK(hipMemcpyAsync(g_h_in.p, in_base + in_off[g.idx[0]], tot, hipMemcpyHostToDevice, g_stream));
+    } else {
+      for (size_t i = 0; i < gc; i++) {
+        const size_t n = in_off[g.idx[i] + 1] - in_off[g.idx[i]];
+        if (n)
+          HIPCHK(hipMemcpyAsync((uint8_t *)g_h_in.p + off[i], in_base + in_off[g.idx[i]], n, hipMemcpyHostToDevice,
+                                g_stream));
+      }
+    }
+    HIPCHK(hipMemcpyAsync(g_h_off.p, off.data(), (gc + 1) * 8, hipMemcpyHostToDevice, g_stream));
+    if (int rc = compress_dev_locked((const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, gc, g.max_len, fmt, lv,
+                                     strategy, dict, (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
+                                     (uint8_t *)g_h_aux8.p))
+      return rc;
+    std::vector<uint32_t> lens(gc);
+    std::vector<uint8_t> pads(gc);
+    HIPCHK(hipMemcpyAsync(lens.data(), g_h_len.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(pads.data(), g_h_aux8.p, gc, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (size_t i = 0; i < gc; i++) {
+      out_len[g.idx[i]] = lens[i];
+      pad_bits[g.idx[i]] = pads[i];
+      HIPCHK(hipMemcpyAsync(out_base + g.idx[i] * out_stride, (uint8_t *)g_h_out.p + i * out_stride, lens[i],
+                            hipMemcpyDeviceToHost, g_stream));
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+  }
+  return 0;
+}
+
+int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
+                         const ldh_dict *dict, uint8_t *out_base, size_t out_stride, uint32_t *out_len,
+                         uint32_t *bytes_left, int32_t *status) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (count == 0) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
+  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
+  if (int rc = ensure(g_h_aux32a, count * 4 + 64)) return rc;
+  if (int rc = ensure(g_h_aux32b, count * 4 + 64)) return rc;
+  if (int rc = decompress_dev_locked((const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, count, fmt, dict,
+                                     (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
+                                     (uint32_t *)g_h_aux32a.p, (int32_t *)g_h_aux32b.p))
+    return rc;
+  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(bytes_left, g_h_aux32a.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(status, g_h_aux32b.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  for (size_t s = 0; s < count; s++)
+    if (status[s] == 0 && out_len[s])
+      HIPCHK(hipMemcpyAsync(out_base + s * out_stride, (uint8_t *)g_h_out.p + s * out_stride, out_len[s],
+                            hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+int ldh_adler32_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint32_t *adler) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!count) return 0;
+  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
+  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
+  LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)g_h_in.p,
+         (const uint64_t *)g_h_off.p, (uint64_t)0, (const uint32_t *)nullptr, (uint32_t *)g_h_len.p);
+  HIPCHK(hipMemcpyAsync(adler, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+int ldh_print6_encode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint8_t *out_base,
+                            size_t out_stride, uint32_t *out_len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  for (size_t s = 0; s < count; s++)
+    if (((in_off[s + 1] - in_off[s]) * 8 + 5) / 6 > out_stride)
+      return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
+  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
+  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
+  LAUNCH("k_print6_encode", k_print6_encode, (uint32_t)count, kP6Threads, 0, (const uint8_t *)g_h_in.p,
+         (const uint64_t *)g_h_off.p, (uint8_t *)g_h_out.p, (uint64_t)out_stride, (uint32_t *)g_h_len.p);
+  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+int ldh_print6_decode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint8_t *out_base,
+                            size_t out_stride, uint32_t *out_len, uint8_t *ok) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  for (size_t s = 0; s < count; s++)
+    if ((in_off[s + 1] - in_off[s]) * 3 / 4 + 3 > out_stride)
+      return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
+  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
+  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
+  if (int rc = ensure(g_h_aux8, count + 64)) return rc;
+  LAUNCH("k_print6_decode", k_print6_decode, (uint32_t)count, kP6Threads, 0, (const uint8_t *)g_h_in.p,
+         (const uint64_t *)g_h_off.p, (uint8_t *)g_h_out.p, (uint64_t)out_stride, (uint32_t *)g_h_len.p,
+         (uint8_t *)g_h_aux8.p);
+  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(ok, g_h_aux8.p, count, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+// ---- single-string forms ------------------------------------------------------
+int ldh_compress(const uint8_t *in, size_t n, int fmt, int level, int strategy, const ldh_dict *dict,
+                 uint8_t *out, size_t cap, size_t *out_len, int *pad_bits) {
+  const uint64_t off[2] = {0, n};
+  const size_t stride = ldh_compress_bound(n);
+  std::vector<uint8_t> tmp(stride);
+  uint32_t ol = 0;
+  uint8_t pb = 0;
+  static const uint8_t empty = 0;
+  int rc = ldh_compress_batch(in ? in : &empty, off, 1, fmt, level, strategy, dict, tmp.data(), stride, &ol, &pb);
+  if (rc) return rc;
+  if (out_len) *out_len = ol;
+  if (pad_bits) *pad_bits = pb;
+  if (ol > cap) return fail(LDH_E_CAPACITY, "output needs %u bytes, cap is %zu", ol, cap);
+  memcpy(out, tmp.data(), ol);
+  return 0;
+}
+
+int ldh_decompress(const uint8_t *in, size_t n, int fmt, const ldh_dict *dict, uint8_t *out, size_t cap,
+                   size_t *out_len, size_t *bytes_left, int *status) {
+  const uint64_t off[2] = {0, n};
+  const size_t stride = round_up(std::max<size_t>(cap, 16), 16);
+  std::vector<uint8_t> tmp(stride);
+  uint32_t ol = 0, bl = 0;
+  int32_t st = 0;
+  static const uint8_t empty = 0;
+  int rc = ldh_decompress_batch(in ? in : &empty, off, 1, fmt, dict, tmp.data(), stride, &ol, &bl, &st);
+  if (rc) return rc;
+  if (st == 0 && ol > cap) st = LDH_STATUS_OUTPUT_FULL;
+  if (status) *status = st;
+  if (out_len) *out_len = ol;
+  if (bytes_left) *bytes_left = bl;
+  if (st == 0 && ol) memcpy(out, tmp.data(), ol);
+  return 0;
+}
+
+int ldh_adler32(const uint8_t *s, size_t n, uint32_t *adler) {
+  const uint64_t off[2] = {0, n};
+  static const uint8_t empty = 0;
+  return ldh_adler32_batch(s ? s : &empty, off, 1, adler);
+}
+
+int ldh_print6_encode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+  const uint64_t off[2] = {0, n};
+  const size_t stride = round_up((n * 8 + 5) / 6 + 16, 16);
+  std::vector<uint8_t> tmp(stride);
+  uint32_t ol = 0;
+  static const uint8_t empty = 0;
+  int rc = ldh_print6_encode_batch(in ? in : &empty, off, 1, tmp.data(), stride, &ol);
+  if (rc) return rc;
+  if (out_len) *out_len = ol;
+  if (ol > cap) return fail(LDH_E_CAPACITY, "output needs %u bytes, cap is %zu", ol, cap);
+  memcpy(out, tmp.data(), ol);
+  return 0;
+}
+
+int ldh_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, int *ok) {
+  const uint64_t off[2] = {0, n};
+  const size_t stride = round_up(n * 3 / 4 + 16, 16);
+  std::vector<uint8_t> tmp(stride);
+  uint32_t ol = 0;
+  uint8_t k = 0;
+  static const uint8_t empty = 0;
+  int rc = ldh_print6_decode_batch(in ? in : &empty, off, 1, tmp.data(), stride, &ol, &k);
+  if (rc) return rc;
+  if (ok) *ok = k;
+  if (out_len) *out_len = ol;
+  if (k && ol > cap) return fail(LDH_E_CAPACITY, "output needs %u bytes, cap is %zu", ol, cap);
+  if (k) memcpy(out, tmp.data(), ol);
+  return 0;
+}
+
+// ---- measurement -----------------------------------------------------------------
+int ldh_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  prof_drain();
+  g_prof = on != 0;
+  return 0;
+}
+int ldh_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  prof_drain();
+  g_prof_entries.clear();
+  return 0;
+}
+int ldh_profile_count(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  prof_drain();
+  return (int)g_prof_entries.size();
+}
+int ldh_profile_get(int index, char *name, size_t name_cap, double *ms, uint64_t *launches) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  prof_drain();
+  if (index < 0 || index >= (int)g_prof_entries.size()) return fail(LDH_E_ARG, "bad profile index");
+  if (name && name_cap) {
+    strncpy(name, g_prof_entries[index].name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (ms) *ms = g_prof_entries[index].ms;
+  if (launches) *launches = g_prof_entries[index].launches;
+  return 0;
+}
+int ldh_timer_start(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  HIPCHK(hipEventRecord(g_t0, g_stream));
+  return 0;
+}
+int ldh_timer_stop(double *ms) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  HIPCHK(hipEventRecord(g_t1, g_stream));
+  HIPCHK(hipEventSynchronize(g_t1));
+  float f = 0;
+  HIPCHK(hipEventElapsedTime(&f, g_t0, g_t1));
+  if (ms) *ms = f;
+  return 0;
+}
+
+// ---- inspection ---------------------------------------------------------------------
+int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!g_have_last || stream >= g_last.count) return fail(LDH_E_ARG, "no such stream in the last batch");
+  const Batch &B = g_last;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case 0: src = B.prevd + stream * B.nvp; bytes = 2ull * B.nvp; break;
+    case 1: src = B.bufB + stream * B.nvp; bytes = 4ull * B.nvp; break;
+    case 2: src = B.bufA + stream * B.nvp; bytes = 4ull * B.nvp; break;
+    case 3: src = B.blocks + stream * B.max_blocks; bytes = (size_t)B.max_blocks * sizeof(BlockInfo); break;
+    case 4: src = B.vbuf + stream * (size_t)(B.nvp + kVPad); bytes = B.nvp + kVPad; break;
+    default: return fail(LDH_E_ARG, "bad what");
+  }
+  if (bytes > cap_bytes) bytes = cap_bytes;
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  if (got_bytes) *got_bytes = bytes;
+  return 0;
+}
+
+}  // extern "C"
