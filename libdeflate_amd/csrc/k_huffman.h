@@ -365,6 +365,7 @@ __global__ void k_plan(Batch B) {
   uint32_t *out32 = (uint32_t *)(B.out + (size_t)s * B.out_stride);
   uint64_t total = 0;
   if (B.fmt == 1) total = B.dict ? 48 : 16;  // CMF, FLG, DICTID (LD:1976-2001)
+  out32[0] = 0;  // the zlib header rides with block 0 and is OR-ed in as well
   for (uint32_t b = 0; b < nblk; b++) {
     BlockInfo *bi = &B.blocks[(size_t)s * B.max_blocks + b];
     const uint32_t bs = block_start(b), be = block_end(b, n);

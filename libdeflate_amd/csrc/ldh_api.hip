@@ -236,6 +236,14 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     Batch Bz = B;
     Bz.dict = dict ? dict->d_bytes : nullptr;
 
+    if (getenv("LDH_POISON")) {  // test hook: no kernel may depend on what a buffer held before
+      HIPCHK(hipMemsetAsync(g_vbuf.p, 0xA5, g_vbuf.cap, g_stream));
+      HIPCHK(hipMemsetAsync(g_prevd.p, 0xA5, g_prevd.cap, g_stream));
+      HIPCHK(hipMemsetAsync(g_bufA.p, 0xA5, g_bufA.cap, g_stream));
+      HIPCHK(hipMemsetAsync(g_bufB.p, 0xA5, g_bufB.cap, g_stream));
+      HIPCHK(hipMemsetAsync(g_blocks.p, 0xA5, g_blocks.cap, g_stream));
+      HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
+    }
     // V (and, for the match search, the trigram chains)
     LAUNCH("k_sort_links", k_sort_links, c, kSortThreads, 0, B);  // TODO(round 2): skip the sort for level 0 / huffman_only
     if (level != 0) {

@@ -1,0 +1,325 @@
+"""GPU parity tests: libdeflate_hip.so (through the C ABI, via the Python host mirror) against the
+CPU oracle and the committed golden fixtures.  Bit-exact everywhere (integer / byte work)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from ldtest import (golden, kat, kat_hex, o_adler32, o_compress, o_decompress, o_print6_decode,
+                    o_print6_encode, splitmix64)
+
+pytestmark = pytest.mark.gpu
+
+KAT = kat()
+
+
+@pytest.fixture(scope="module")
+def LD():
+    from libdeflate_amd import LibDeflate
+    return LibDeflate
+
+
+@pytest.fixture(scope="module")
+def B():
+    from libdeflate_amd import batch
+    return batch
+
+
+def _files():
+    return [golden(f) for f in ("item_strings.txt", "smalltest_no_newline.txt", "64kminus1.txt", "64k.txt",
+                                "64kplus1.txt", "encode_6bit_weakaura.txt", "totalrp3.txt")]
+
+
+def _small():
+    rng = np.random.default_rng(7)
+    return [b"", b"a", b"ab", b"abc", b"aaa", b"a" * 1000, bytes(range(256)) + bytes(range(255, -1, -1)),
+            bytes(rng.integers(0, 256, 3000, dtype=np.uint8)), bytes(rng.integers(97, 101, 5000, dtype=np.uint8)),
+            b"abcabcabcabcabcabcabcabc" * 40]
+
+
+# ------------------------------------------------------------------ compress
+
+def test_golden_streams_byte_exact(LD):
+    item, dct = golden("item_strings.txt"), golden("dictionary32768.txt")
+    d = LD.CreateDictionary(dct, 32768, 4072834167)  # tests/Test.lua:382-383
+    assert LD.CompressDeflate(item)[0] == golden("item_strings_deflate.bin")
+    assert LD.CompressDeflateWithDict(item, d)[0] == golden("item_strings_deflate_with_dict.bin")
+    assert LD.CompressZlib(item) == (golden("item_strings_zlib.bin"), 0)
+    assert LD.CompressZlibWithDict(item, d) == (golden("item_strings_zlib_with_dict.bin"), 0)
+
+
+def test_pinned_sizes(LD):
+    s = bytes(range(256)) + bytes(range(255, -1, -1))
+    e = KAT["sizes_updown"]
+    assert len(LD.CompressDeflate(s)[0]) == e["deflate_default"]
+    assert len(LD.CompressDeflate(s, {"strategy": "fixed"})[0]) == e["deflate_fixed"]
+    assert len(LD.CompressZlib(s, {"strategy": "fixed"})[0]) == e["zlib_fixed"]
+    assert len(LD.CompressDeflate(s, {"strategy": "dynamic"})[0]) == e["deflate_dynamic"]
+    assert len(LD.CompressZlib(s, {"strategy": "dynamic"})[0]) == e["zlib_dynamic"]
+    a = b"a" * 1000
+    e = KAT["sizes_a1000"]
+    assert len(LD.CompressDeflate(a)[0]) == e["deflate_default"]
+    assert len(LD.CompressDeflate(a, {"strategy": "huffman_only"})[0]) == e["deflate_huffman_only"]
+    assert len(LD.CompressZlib(a)[0]) == e["zlib_default"]
+    assert len(LD.CompressZlib(a, {"strategy": "huffman_only"})[0]) == e["zlib_huffman_only"]
+    sm = golden("smalltest_no_newline.txt")
+    assert [len(LD.CompressDeflate(sm, {"level": l})[0]) for l in range(10)] == KAT["smalltest_bounds"]
+    assert LD.CompressDeflate(b"") == (bytes.fromhex("03fc"), 6)
+    assert LD.CompressZlib(b"") == (bytes.fromhex("789c03fc00000001"), 0)
+
+
+@pytest.mark.parametrize("level", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_compress_matches_oracle_all_levels(B, level):
+    cases = _small() + _files()
+    if level == 9:
+        cases = [c for c in cases if len(c) < 70000]
+    for fmt in (0, 1):
+        got = B.compress_batch(cases, fmt=fmt, level=level)
+        for s, g in zip(cases, got):
+            assert g == o_compress(s, zlib=bool(fmt), level=level), (level, fmt, len(s))
+
+
+@pytest.mark.parametrize("strategy", ["fixed", "huffman_only", "dynamic"])
+def test_compress_strategies(B, strategy):
+    cases = _small() + _files()[:2]
+    for level in (0, 1, 5, None):
+        got = B.compress_batch(cases, level=level, strategy=strategy)
+        for s, g in zip(cases, got):
+            assert g == o_compress(s, level=level, strategy=strategy), (level, strategy, len(s))
+
+
+@pytest.mark.parametrize("dlen", [1, 2, 3, 4, 100, 257, 258, 259, 260, 1000, 32768])
+def test_compress_dictionary(LD, B, dlen):
+    full = golden("dictionary32768.txt")
+    dct = full[-dlen:]
+    d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
+    rng = np.random.default_rng(dlen)
+    cases = [b"", dct, dct[:1], dct[-3:] * 3, golden("item_strings.txt"), dct[len(dct) // 2:] + b"xyz" + dct[: len(dct) // 2],
+             bytes(rng.integers(0, 256, 500, dtype=np.uint8)), golden("smalltest_no_newline.txt"), golden("64kplus1.txt")]
+    for level in (1, 2, 3, 5, 7):
+        for fmt in (0, 1):
+            got = B.compress_batch(cases, fmt=fmt, level=level, dictionary=d)
+            for s, g in zip(cases, got):
+                assert g == o_compress(s, zlib=bool(fmt), level=level, dict=dct), (dlen, level, fmt, len(s))
+
+
+def test_ragged_batch_default_levels(B):
+    # one call, streams of very different sizes: default level is resolved per stream (LD:1782-1790)
+    v = splitmix64(99, 300)
+    rng = np.random.default_rng(5)
+    base = golden("totalrp3.txt") + golden("encode_6bit_weakaura.txt")
+    cases = []
+    for i in range(300):
+        n = int(v[i] % 6000) if i % 7 else int(v[i] % 90000)
+        o = int((v[i] >> 20) % (len(base) - n - 1))
+        cases.append(base[o: o + n])
+    cases += [b"", b"x", bytes(rng.integers(0, 256, 70000, dtype=np.uint8))]
+    got = B.compress_batch(cases, level=None)
+    for s, g in zip(cases, got):
+        assert g == o_compress(s), len(s)
+    got = B.compress_batch(cases, fmt=1, level=5)
+    for s, g in zip(cases, got):
+        assert g == o_compress(s, zlib=True, level=5), len(s)
+
+
+def test_synthetic_configs(B):
+    from libdeflate_amd import synth
+    text = [r.tobytes() for r in synth.text_streams(6, 131072)]      # BASELINE configs[2] shape
+    addon = [r.tobytes() for r in synth.addon_streams(256, 4096)]    # BASELINE configs[1] shape
+    for level in (1, 5, 8):
+        for s, g in zip(text, B.compress_batch(text, level=level)):
+            assert g == o_compress(s, level=level), level
+        for s, g in zip(addon, B.compress_batch(addon, level=level)):
+            assert g == o_compress(s, level=level), level
+
+
+def test_no_dependence_on_stale_buffers(B):
+    cases = _small() + _files()
+    os.environ["LDH_POISON"] = "1"
+    try:
+        for level, fmt in ((5, 0), (1, 1), (0, 1), (8, 0)):
+            for s, g in zip(cases, B.compress_batch(cases, fmt=fmt, level=level)):
+                assert g == o_compress(s, zlib=bool(fmt), level=level), (level, fmt, len(s))
+    finally:
+        del os.environ["LDH_POISON"]
+
+
+def test_full_size_roundtrip_property(B):
+    # size-independent property at the bench's stream size: inflate(deflate(x)) == x, on the GPU
+    from libdeflate_amd import synth
+    text = [r.tobytes() for r in synth.text_streams(64, 131072, first_stream=1000)]
+    for level in (1, 5, 8):
+        comp = [c for c, _ in B.compress_batch(text, level=level)]
+        back = B.decompress_batch(comp, max_out=131072)
+        assert [d for d, _ in back] == text
+        assert all(left == 0 for _, left in back)
+
+
+# ------------------------------------------------------------------ decompress
+
+def test_inflate_kat_vectors(LD):
+    for v in KAT["inflate"]:
+        raw = kat_hex(v["in"])
+        f = LD.DecompressZlib if v["zlib"] else LD.DecompressDeflate
+        data, second = f(raw)
+        assert data == kat_hex(v["out"]), v["in"][:60]
+        assert (data, second) == o_decompress(raw, zlib=bool(v["zlib"])), v["in"][:60]  # same status code too
+
+
+def test_inflate_dict_vectors(LD):
+    dct = b"abcdefgh"
+    d = LD.CreateDictionary(dct, 8, 0x0E000325)
+    for v in KAT["inflate_dict_abcdefgh"]:
+        raw = kat_hex(v["in"])
+        got = LD.DecompressZlibWithDict(raw, d) if v["use_dict"] else LD.DecompressZlib(raw)
+        assert got[0] == kat_hex(v["out"]), v
+        assert got == o_decompress(raw, zlib=True, dict=dct if v["use_dict"] else None)
+
+
+def test_inflate_golden_streams(LD):
+    item, dct = golden("item_strings.txt"), golden("dictionary32768.txt")
+    d = LD.CreateDictionary(dct, 32768, 4072834167)
+    assert LD.DecompressDeflate(golden("item_strings_deflate.bin")) == (item, 0)
+    assert LD.DecompressDeflateWithDict(golden("item_strings_deflate_with_dict.bin"), d) == (item, 0)
+    assert LD.DecompressZlib(golden("item_strings_zlib.bin")) == (item, 0)
+    assert LD.DecompressZlibWithDict(golden("item_strings_zlib_with_dict.bin"), d) == (item, 0)
+
+
+def test_inflate_own_and_foreign_streams(B):
+    cases = _small() + _files()
+    comp, want = [], []
+    for s in cases:
+        for lvl in (0, 1, 5, 8):
+            comp.append(o_compress(s, level=lvl)[0])
+            want.append(s)
+        for st in ("fixed", "huffman_only", "dynamic"):
+            comp.append(o_compress(s, level=5, strategy=st)[0])
+            want.append(s)
+        for zl in (1, 6, 9):  # zlib-made streams (tests/Test.lua:574-606)
+            co = zlib.compressobj(zl, zlib.DEFLATED, -15)
+            comp.append(co.compress(s) + co.flush())
+            want.append(s)
+    got = B.decompress_batch(comp)
+    for w, g in zip(want, got):
+        assert g == (w, 0)
+    zcomp = [zlib.compress(s, 6) for s in cases] + [o_compress(s, zlib=True, level=5)[0] for s in cases]
+    got = B.decompress_batch(zcomp, fmt=1)
+    for w, g in zip(cases + cases, got):
+        assert g == (w, 0)
+
+
+def test_inflate_second_return_and_truncation(B):
+    s = golden("smalltest_no_newline.txt")
+    c = o_compress(s, level=5)[0]
+    z = o_compress(s, zlib=True, level=5)[0]
+    ins = [c + b"\x55" * k for k in range(0, 11)] + [c[:k] for k in range(0, len(c), 97)]
+    for raw, g in zip(ins, B.decompress_batch(ins)):
+        assert g == o_decompress(raw), len(raw)
+    ins = [z + b"\xaa" * k for k in range(0, 11)] + [z[:k] for k in range(0, len(z), 97)] + [z[:-1] + b"\x00"]
+    for raw, g in zip(ins, B.decompress_batch(ins, fmt=1)):
+        assert g == o_decompress(raw, zlib=True), len(raw)
+
+
+def test_inflate_with_dictionary(LD, B):
+    full = golden("dictionary32768.txt")
+    for dlen in (1, 3, 258, 259, 32768):
+        dct = full[-dlen:]
+        d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
+        cases = [b"", dct, golden("item_strings.txt"), dct[-3:] * 5, golden("64kplus1.txt")]
+        for fmt in (0, 1):
+            comp = [o_compress(s, zlib=bool(fmt), level=7, dict=dct)[0] for s in cases]
+            # foreign zlib stream using the dictionary in a later block is Q12 territory; zlib's own
+            o = zlib.compressobj(9, zlib.DEFLATED, 15 if fmt else -15, zdict=dct)
+            comp.append(o.compress(cases[2]) + o.flush())
+            want = cases + [cases[2]]
+            for raw, w, g in zip(comp, want, B.decompress_batch(comp, fmt=fmt, dictionary=d)):
+                assert g == o_decompress(raw, zlib=bool(fmt), dict=dct)
+                assert g == (w, 0)
+
+
+def test_inflate_garbage_matches_oracle(B):
+    # random bytes never crash and give the oracle's (nil, status) or data (tests/Test.lua:2780-2801)
+    raw = splitmix64(4242, 8000).tobytes()
+    ins = [raw[i * 13: i * 13 + 1 + (i % 61)] for i in range(3000)]
+    ins += [bytes([0x78, 0x9C]) + x for x in ins[:500]]
+    for x, g in zip(ins, B.decompress_batch(ins)):
+        assert g == o_decompress(x), x.hex()
+    for x, g in zip(ins, B.decompress_batch(ins, fmt=1)):
+        assert g == o_decompress(x, zlib=True), x.hex()
+
+
+def test_inflate_output_capacity_status(B):
+    from libdeflate_amd import _native as N
+    import ctypes as C
+    s = b"hello " * 100
+    c = o_compress(s, level=5)[0]
+    out = (C.c_ubyte * 64)()
+    ol, bl, st = C.c_size_t(), C.c_size_t(), C.c_int()
+    buf = (C.c_ubyte * len(c)).from_buffer_copy(c)
+    N.check(N.lib.ldh_decompress(buf, len(c), 0, None, out, 64, C.byref(ol), C.byref(bl), C.byref(st)))
+    assert st.value == 1  # LDH_STATUS_OUTPUT_FULL
+
+
+# ------------------------------------------------------------------ adler / print codec
+
+def test_adler32(LD, B):
+    for v in KAT["adler32"]:
+        assert LD.Adler32(v["str"].encode()) == v["adler"]
+    for f, want in KAT["adler32_files"].items():
+        assert LD.Adler32(golden(f)) == want
+    cases = _small() + _files() + [b"\xff" * 300000]
+    assert B.adler32_batch(cases) == [o_adler32(s) for s in cases]
+    assert B.adler32_batch(cases) == [zlib.adler32(s) for s in cases]
+
+
+def test_print6(LD, B):
+    dec, enc = golden("decode_6bit_weakaura.bin"), golden("encode_6bit_weakaura.txt")
+    assert LD.EncodeForPrint(dec) == enc
+    assert LD.DecodeForPrint(enc) == dec
+    assert LD.DecodeForPrint(b" \n\t" + enc + b"\r\n ") == dec
+    assert LD.DecodeForPrint(b"a") is None and LD.DecodeForPrint(b"ab!d") is None
+    assert LD.DecodeForPrint(b"") == b"" and LD.EncodeForPrint(b"") == b""
+    raw = splitmix64(77, 4000).tobytes()
+    ins = [raw[i * 5: i * 5 + (i % 50)] for i in range(600)]
+    encs = B.print6_encode_batch(ins)
+    assert encs == [o_print6_encode(s) for s in ins]
+    assert B.print6_decode_batch(encs) == ins
+    noisy = [b"  " + e + b"\n" for e in encs] + [e[:3] + b"#" + e[3:] for e in encs if len(e) > 3] + [b" ", b"\x7f(a"]
+    assert B.print6_decode_batch(noisy) == [o_print6_decode(s) for s in noisy]
+
+
+# ------------------------------------------------------------------ device-resident API
+
+def test_device_resident_api_matches_host_api(B):
+    import torch
+    from libdeflate_amd import synth
+    rows = synth.text_streams(32, 20000)
+    strings = [r.tobytes() for r in rows]
+    data = torch.from_numpy(rows.reshape(-1).copy()).cuda()
+    off = (torch.arange(33, dtype=torch.int64) * 20000).cuda()
+    bt = B.DeviceBatch(data, off, 20000)
+    from libdeflate_amd import _native as N
+    stride = N.lib.ldh_compress_bound(20000)
+    out = torch.empty(32 * stride, dtype=torch.uint8, device="cuda")
+    out_len = torch.zeros(32, dtype=torch.int32, device="cuda")
+    pad = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    B.device_compress(bt, out, stride, out_len, pad, level=5)
+    B.sync()
+    lens = out_len.cpu().numpy()
+    o = out.cpu().numpy()
+    for i, s in enumerate(strings):
+        assert (o[i * stride: i * stride + lens[i]].tobytes(), int(pad[i])) == o_compress(s, level=5)
+    # decompress on the device: compact the compressed streams first
+    coff = torch.zeros(33, dtype=torch.int64)
+    coff[1:] = torch.cumsum(torch.from_numpy(lens.astype(np.int64)), 0)
+    comp = torch.cat([out[i * stride: i * stride + int(lens[i])] for i in range(32)])
+    cb = B.DeviceBatch(comp, coff.cuda(), int(lens.max()))
+    dout = torch.empty(32 * 20000, dtype=torch.uint8, device="cuda")
+    dlen = torch.zeros(32, dtype=torch.int32, device="cuda")
+    left = torch.zeros(32, dtype=torch.int32, device="cuda")
+    status = torch.zeros(32, dtype=torch.int32, device="cuda")
+    B.device_decompress(cb, dout, 20000, dlen, left, status)
+    B.sync()
+    assert int(status.abs().sum()) == 0 and int(left.sum()) == 0
+    assert torch.equal(dout, data)
