@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X:
+input GB/s, compress + decompress, level 5, batched 128 KB strings.
+
+One step = one pass of the hot path over one device-resident batch:
+CompressDeflate(level 5) of every stream, then DecompressDeflate of every result.
+Inputs are generated on the device (synthetic G-text) and are resident in HBM
+before the timed region; nothing crosses PCIe inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--level L]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is computed live for the dominant kernel of the
+timed region from HIP events on the library's stream; `cpu_baseline` is the CPU oracle
+(a C port of the reference algorithm, the reference itself being Lua and no Lua VM present)
+on a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STREAM_LEN = 131072
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+SEED = 0x4C69624465666C61
+
+
+def gen_text_device(torch, count, length, device, seed):
+    """G-text on the device: Zipf(1.1) words over the 4096-word vocabulary of synth.py,
+    punctuation every 60-80 bytes.  Returns uint8 tensor (count*length)."""
+    import numpy as np
+    from libdeflate_amd import synth
+    wl, wt = synth._vocab()
+    nw = len(wl)
+    table = np.full((nw, 11), 32, dtype=np.uint8)
+    mask = np.zeros((nw, 11), dtype=bool)
+    for i in range(nw):
+        table[i, : wl[i]] = wt[i, : wl[i]]
+        mask[i, : wl[i] + 1] = True
+    g = torch.Generator(device=device)
+    g.manual_seed(seed & 0x7FFFFFFFFFFFFFFF)
+    p = torch.arange(1, nw + 1, dtype=torch.float64, device=device) ** -1.1
+    cdf = torch.cumsum(p / p.sum(), 0).to(torch.float32)
+    t_table = torch.from_numpy(table).to(device)
+    t_mask = torch.from_numpy(mask).to(device)
+    total = count * length
+    out = torch.empty(total, dtype=torch.uint8, device=device)
+    filled = 0
+    chunk_words = 1 << 24
+    while filled < total:
+        u = torch.rand(chunk_words, device=device, generator=g)
+        idx = torch.searchsorted(cdf, u).clamp_(max=nw - 1)
+        flat = t_table[idx][t_mask[idx]]
+        take = min(flat.numel(), total - filled)
+        out[filled: filled + take] = flat[:take]
+        filled += take
+    # sentence / line breaks
+    nbreak = total // 60 + 2
+    gaps = torch.randint(60, 81, (nbreak,), device=device, generator=g)
+    pos = torch.cumsum(gaps, 0)
+    pos = pos[pos < total]
+    punct = torch.tensor(list(b".,;\n\n"), dtype=torch.uint8, device=device)
+    out[pos] = punct[torch.randint(0, 5, (pos.numel(),), device=device, generator=g)]
+    return out
+
+
+def cpu_baseline(host_rows, level, seconds_target=12.0):
+    """The CPU oracle (C port of the reference's algorithm) on the host cores, round trip,
+    over a bounded sample of the batch.  Returns dict for the JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ldtest as T
+    cores = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+    rows = [r.tobytes() for r in host_rows]
+
+    def work(s):
+        c, _ = T.o_compress(s, level=level)
+        d, left = T.o_decompress(c, cap=len(s))
+        assert d == s and left == 0
+        return len(s)
+
+    # calibrate on one stream, then size the sample to ~seconds_target of wall time
+    t0 = time.time()
+    work(rows[0])
+    per = max(time.time() - t0, 1e-4)
+    nsample = int(max(cores, min(len(rows), seconds_target * cores / per)))
+    sample = rows[:nsample]
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=cores) as ex:  # ctypes releases the GIL inside the oracle
+        nbytes = sum(ex.map(work, sample))
+    dt = time.time() - t0
+    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": "%d of the batch's 128 KiB streams, compress(level %d)+decompress by oracle/ld_oracle.c, "
+                      "%d threads, %.1f s" % (nsample, level, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=8192, help="streams per GPU (each 131072 B)")
+    ap.add_argument("--level", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from libdeflate_amd import _native as N
+    from libdeflate_amd import batch as B
+    N.init(local_rank)
+
+    S, L = args.streams, STREAM_LEN
+    data = gen_text_device(torch, S, L, dev, SEED ^ rank)
+    off = torch.arange(S + 1, dtype=torch.int64, device=dev) * L
+    bt = B.DeviceBatch(data, off, L)
+    stride = N.lib.ldh_compress_bound(L)
+    comp = torch.empty(S * stride, dtype=torch.uint8, device=dev)
+    comp_len = torch.zeros(S, dtype=torch.int32, device=dev)
+    pad = torch.zeros(S, dtype=torch.uint8, device=dev)
+    back = torch.empty(S * L, dtype=torch.uint8, device=dev)
+    back_len = torch.zeros(S, dtype=torch.int32, device=dev)
+    left = torch.zeros(S, dtype=torch.int32, device=dev)
+    status = torch.zeros(S, dtype=torch.int32, device=dev)
+
+    def step():
+        B.device_compress(bt, comp, stride, comp_len, pad, fmt=0, level=args.level)
+        B.device_decompress_slots(comp, stride, comp_len, S, back, L, back_len, left, status, fmt=0)
+
+    def fence():
+        B.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    B.profile(True)
+    B.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    B.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = B.profile_report()
+    B.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness inside the same run: exact round trip of every stream, oracle bytes on a sample
+    ok = bool(torch.equal(back, data)) and int(status.abs().sum()) == 0 and int(left.sum()) == 0
+    comp_bytes = int(comp_len.sum().item())
+    nsamp = 4
+    host_rows = data[: max(nsamp, 4096) * L].view(-1, L)[: 4096 if not args.no_cpu_baseline else nsamp].cpu().numpy()
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ldtest as T
+        lens = comp_len[:nsamp].cpu().numpy()
+        cbuf = comp[: nsamp * stride].cpu().numpy()
+        for i in range(nsamp):
+            want, _ = T.o_compress(host_rows[i].tobytes(), level=args.level)
+            ok = ok and cbuf[i * stride: i * stride + int(lens[i])].tobytes() == want
+    if dist is not None:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+
+    if rank == 0:
+        in_bytes = S * L * args.steps * world
+        value = in_bytes / dt / 1e9
+        # dominant kernel of the timed region
+        name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+        compress_kernels = ("k_sort_links", "k_match_lazy", "k_parse_lazy", "k_lz_greedy", "k_tokens_literal",
+                            "k_histogram", "k_huffman", "k_plan", "k_bitpack")
+        # algorithmic bytes per launch: compress N_in + N_out, decompress N_comp + N_out
+        alg = S * L + comp_bytes
+        avg_s = ms / 1e3 / max(launches, 1)
+        achieved = alg / avg_s / 1e9
+        line = {
+            "metric": "input GB/s compress+decompress, level %d, batched 128 KB strings" % args.level,
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d x %d B G-text streams per GPU (SURVEY 8.d), CompressDeflate level %d + "
+                                   "DecompressDeflate, device-resident" % (S, L, args.level),
+                       "streams_per_gpu": S, "stream_bytes": L, "level": args.level, "seed": hex(SEED),
+                       "compress_ratio": S * L / max(comp_bytes, 1), "verified": ok,
+                       "phase_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
+                       "compress_GBps": S * L * args.steps / 1e6 / max(sum(v[0] for k, v in prof.items() if k in compress_kernels), 1e-9),
+                       "decompress_GBps": S * L * args.steps / 1e6 / max(sum(v[0] for k, v in prof.items() if k not in compress_kernels), 1e-9)},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host_rows, args.level)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

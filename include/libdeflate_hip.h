@@ -110,6 +110,13 @@ int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size
                              int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
                              uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status);
 
+/* Same, for inputs laid out as ldh_compress_batch_dev leaves them: stream s is
+ * d_in + s*in_stride, d_in_len[s] bytes (so a device-resident round trip needs no repacking). */
+int ldh_decompress_slots_dev(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_len,
+                             size_t count, int fmt, const ldh_dict *dict, uint8_t *d_out,
+                             size_t out_stride, uint32_t *d_out_len, uint32_t *d_bytes_left,
+                             int32_t *d_status);
+
 int ldh_adler32_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count,
                       uint32_t *adler);
 int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,

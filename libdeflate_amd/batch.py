@@ -141,6 +141,16 @@ def device_decompress(batch, out, out_stride, out_len, bytes_left, status, fmt=0
                                            status.data_ptr()))
 
 
+def device_decompress_slots(data, in_stride, in_len, count, out, out_stride, out_len, bytes_left, status, fmt=0,
+                            dictionary=None):
+    """Decompress streams left in strided slots by device_compress (no repacking)."""
+    N.init()
+    N.check(N.lib.ldh_decompress_slots_dev(data.data_ptr(), in_stride, in_len.data_ptr(), count, fmt,
+                                           dictionary.handle() if dictionary is not None else None,
+                                           out.data_ptr(), out_stride, out_len.data_ptr(), bytes_left.data_ptr(),
+                                           status.data_ptr()))
+
+
 def sync():
     N.check(N.lib.ldh_sync())
 

@@ -30,7 +30,9 @@ struct DecTab {
 
 struct InflateArgs {
   const uint8_t *in;
-  const uint64_t *in_off;
+  const uint64_t *in_off;   // stream s = in[in_off[s] .. in_off[s+1])            (in_len == nullptr)
+  const uint32_t *in_len;   // or: stream s = in + s*in_stride, in_len[s] bytes  (slots)
+  uint64_t in_stride;
   uint32_t count;
   int fmt;
   const uint8_t *dict;
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
   __shared__ DecTab LT, DT;
   __shared__ uint8_t lens[320 + 32];
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
-  const uint64_t off = A.in_off[s];
-  const uint32_t n = (uint32_t)(A.in_off[s + 1] - off);
+  const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
+  const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
   BitReader R;
   br_init(R, A.in + off, n, lane);
   OutState O;

@@ -273,7 +273,8 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
 }
 
 // ---- decompress -------------------------------------------------------------
-int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, int fmt,
+int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                          size_t in_stride, size_t count, int fmt,
                           const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
                           uint32_t *d_bytes_left, int32_t *d_status) {
   if (int rc = check_init()) return rc;
@@ -285,6 +286,8 @@ int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t 
   InflateArgs A{};
   A.in = d_in;
   A.in_off = d_in_off;
+  A.in_len = d_in_len;
+  A.in_stride = in_stride;
   A.count = (uint32_t)count;
   A.fmt = fmt;
   A.dict = dict ? dict->d_bytes : nullptr;
@@ -440,8 +443,17 @@ int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size
                              const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
                              uint32_t *d_bytes_left, int32_t *d_status) {
   std::lock_guard<std::mutex> lk(g_mu);
-  return decompress_dev_locked(d_in, d_in_off, count, fmt, dict, d_out, out_stride, d_out_len, d_bytes_left,
-                               d_status);
+  return decompress_dev_locked(d_in, d_in_off, nullptr, 0, count, fmt, dict, d_out, out_stride, d_out_len,
+                               d_bytes_left, d_status);
+}
+
+int ldh_decompress_slots_dev(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_len, size_t count,
+                             int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
+                             uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!d_in_len) return fail(LDH_E_ARG, "d_in_len is required");
+  return decompress_dev_locked(d_in, nullptr, d_in_len, in_stride, count, fmt, dict, d_out, out_stride, d_out_len,
+                               d_bytes_left, d_status);
 }
 
 int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint32_t *d_adler) {
@@ -573,7 +585,7 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
   if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
   if (int rc = ensure(g_h_aux32a, count * 4 + 64)) return rc;
   if (int rc = ensure(g_h_aux32b, count * 4 + 64)) return rc;
-  if (int rc = decompress_dev_locked((const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, count, fmt, dict,
+  if (int rc = decompress_dev_locked((const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, nullptr, 0, count, fmt, dict,
                                      (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
                                      (uint32_t *)g_h_aux32a.p, (int32_t *)g_h_aux32b.p))
     return rc;
