@@ -1,0 +1,218 @@
+--[[ LibDeflate-compatible shim over libdeflate_hip.so (LuaJIT 2.1 FFI).
+
+Drop-in for require("LibDeflate") on the hot path only: CompressDeflate / CompressZlib /
+Compress*WithDict / DecompressDeflate / DecompressZlib / Decompress*WithDict / Adler32 /
+CreateDictionary / EncodeForPrint / DecodeForPrint.  Argument validation and the usage-error
+strings are kept in Lua exactly as the reference words them; everything after validation goes
+through the C ABI of include/libdeflate_hip.h.  The batched entry point is returned as a SECOND
+value of require (the reference's TestExported demands exactly its 22 keys on the first table).
+
+NOT TESTED in the build image: no Lua/LuaJIT interpreter exists there (SURVEY.md 8.c).
+]]
+local ffi = require("ffi")
+ffi.cdef [[
+typedef struct ldh_dict ldh_dict;
+int ldh_init(int device);
+const char *ldh_last_error(void);
+size_t ldh_compress_bound(size_t n);
+ldh_dict *ldh_dict_create(const uint8_t *bytes, size_t n);
+void ldh_dict_free(ldh_dict *d);
+int ldh_compress(const uint8_t *in, size_t n, int fmt, int level, int strategy, const ldh_dict *dict,
+                 uint8_t *out, size_t cap, size_t *out_len, int *pad_bits);
+int ldh_decompress(const uint8_t *in, size_t n, int fmt, const ldh_dict *dict, uint8_t *out, size_t cap,
+                   size_t *out_len, size_t *bytes_left, int *status);
+int ldh_adler32(const uint8_t *s, size_t n, uint32_t *adler);
+int ldh_print6_encode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+int ldh_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, int *ok);
+int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt, int level,
+                       int strategy, const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
+                       uint32_t *out_len, uint8_t *pad_bits);
+int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
+                         const ldh_dict *dict, uint8_t *out_base, size_t out_stride, uint32_t *out_len,
+                         uint32_t *bytes_left, int32_t *status);
+]]
+local C = ffi.load(os.getenv("LIBDEFLATE_HIP_SO") or "libdeflate_hip.so")
+local function check(rc)
+  if rc ~= 0 then error("libdeflate_hip: " .. ffi.string(C.ldh_last_error()), 3) end
+end
+check(C.ldh_init(tonumber(os.getenv("LIBDEFLATE_HIP_DEVICE") or "0")))
+
+local LibDeflate = {_VERSION = "1.0.2-release", _MAJOR = "LibDeflate", _MINOR = 3,
+                    _COPYRIGHT = "LibDeflate 1.0.2-release Copyright (C) 2018-2021 Haoqian He. zlib License"}
+local STRATEGY = {fixed = 1, huffman_only = 2, dynamic = 3}
+local LEVEL_OK = {[0]=true,true,true,true,true,true,true,true,true,true}
+local dict_handles = setmetatable({}, {__mode = "k"})  -- dictionary table -> device handle
+
+local function IsValidDictionary(d)  -- LibDeflate.lua:602-615
+  if type(d) ~= "table" then
+    return false, ("'dictionary' - table expected got '%s'."):format(type(d))
+  end
+  if type(d.adler32) ~= "number" or type(d.string_table) ~= "table" or type(d.strlen) ~= "number"
+    or d.strlen <= 0 or d.strlen > 32768 or d.strlen ~= #d.string_table or type(d.hash_tables) ~= "table" then
+    return false, ("'dictionary' - corrupted dictionary."):format(type(d))
+  end
+  return true, ""
+end
+local function IsValidArguments(str, check_dictionary, dictionary, check_configs, configs)  -- :679-714
+  if type(str) ~= "string" then return false, ("'str' - string expected got '%s'."):format(type(str)) end
+  if check_dictionary then
+    local ok, err = IsValidDictionary(dictionary)
+    if not ok then return false, err end
+  end
+  if check_configs then
+    local t = type(configs)
+    if t ~= "nil" and t ~= "table" then
+      return false, ("'configs' - nil or table expected got '%s'."):format(type(configs))
+    end
+    if t == "table" then
+      for k, v in pairs(configs) do
+        if k ~= "level" and k ~= "strategy" then
+          return false, ("'configs' - unsupported table key in the configs: '%s'."):format(k)
+        elseif k == "level" and not LEVEL_OK[v] then
+          return false, ("'configs' - unsupported 'level': %s."):format(tostring(v))
+        elseif k == "strategy" and v ~= "fixed" and v ~= "huffman_only" and v ~= "dynamic" then
+          return false, ("'configs' - unsupported 'strategy': '%s'."):format(tostring(v))
+        end
+      end
+    end
+  end
+  return true, ""
+end
+
+local function handle_of(dictionary)
+  if not dictionary then return nil end
+  local h = dict_handles[dictionary]
+  if not h then
+    local n = dictionary.strlen
+    local buf = ffi.new("uint8_t[?]", n)
+    for i = 1, n do buf[i - 1] = dictionary.string_table[i] end
+    h = C.ldh_dict_create(buf, n)
+    if h == nil then error("libdeflate_hip: " .. ffi.string(C.ldh_last_error()), 3) end
+    h = ffi.gc(h, C.ldh_dict_free)
+    dict_handles[dictionary] = h
+  end
+  return h
+end
+
+function LibDeflate:Adler32(str)
+  if type(str) ~= "string" then
+    error(("Usage: LibDeflate:Adler32(str): 'str' - string expected got '%s'."):format(type(str)), 2)
+  end
+  local out = ffi.new("uint32_t[1]")
+  check(C.ldh_adler32(str, #str, out))
+  return tonumber(out[0])
+end
+
+function LibDeflate:CreateDictionary(str, strlen, adler32)  -- same table shape as LibDeflate.lua:531-595
+  local pre = "Usage: LibDeflate:CreateDictionary(str, strlen, adler32):"
+  if type(str) ~= "string" then error((pre .. " 'str' - string expected got '%s'."):format(type(str)), 2) end
+  if type(strlen) ~= "number" then error((pre .. " 'strlen' - number expected got '%s'."):format(type(strlen)), 2) end
+  if type(adler32) ~= "number" then error((pre .. " 'adler32' - number expected got '%s'."):format(type(adler32)), 2) end
+  if strlen ~= #str then
+    error((pre .. " 'strlen' does not match the actual length of 'str'. 'strlen': %u, '#str': %u ." ..
+           " Please check if 'str' is modified unintentionally."):format(strlen, #str))
+  end
+  if strlen == 0 then error(pre .. " 'str' - Empty string is not allowed.", 2) end
+  if strlen > 32768 then
+    error((pre .. " 'str' - string longer than 32768 bytes is not allowed. Got %d bytes."):format(strlen), 2)
+  end
+  local actual = self:Adler32(str)
+  if adler32 % 4294967296 ~= actual % 4294967296 then
+    error((pre .. " 'adler32' does not match the actual adler32 of 'str'. 'adler32': %u, 'Adler32(str)': %u ." ..
+           " Please check if 'str' is modified unintentionally."):format(adler32, actual))
+  end
+  local d = {adler32 = adler32, strlen = strlen, string_table = {}, hash_tables = {}}
+  for i = 1, strlen do d.string_table[i] = str:byte(i) end
+  for i = 1, strlen - 2 do  -- kept so that callers / tests that inspect hash_tables keep working
+    local h = d.string_table[i] * 65536 + d.string_table[i + 1] * 256 + d.string_table[i + 2]
+    local t = d.hash_tables[h]
+    if not t then t = {}; d.hash_tables[h] = t end
+    t[#t + 1] = i - strlen
+  end
+  return d
+end
+
+local function compress(str, fmt, dictionary, configs)
+  local level, strategy = -1, 0
+  if configs then
+    if configs.level then level = configs.level end
+    if configs.strategy then strategy = STRATEGY[configs.strategy] end
+  end
+  local cap = tonumber(C.ldh_compress_bound(#str))
+  local out = ffi.new("uint8_t[?]", cap)
+  local ol, pb = ffi.new("size_t[1]"), ffi.new("int[1]")
+  check(C.ldh_compress(str, #str, fmt, level, strategy, handle_of(dictionary), out, cap, ol, pb))
+  return ffi.string(out, ol[0]), pb[0]
+end
+local function decompress(str, fmt, dictionary)
+  local cap = math.max(64, 4 * #str + 64)
+  local h = handle_of(dictionary)
+  while true do
+    local out = ffi.new("uint8_t[?]", cap)
+    local ol, bl, st = ffi.new("size_t[1]"), ffi.new("size_t[1]"), ffi.new("int[1]")
+    check(C.ldh_decompress(str, #str, fmt, h, out, cap, ol, bl, st))
+    if st[0] == 1 then cap = cap * 4  -- LDH_STATUS_OUTPUT_FULL: Lua strings simply grow
+    elseif st[0] ~= 0 then return nil, st[0]
+    else return ffi.string(out, ol[0]), tonumber(bl[0]) end
+  end
+end
+
+local function wrap(name, sig, fmt, with_dict, is_compress)
+  LibDeflate[name] = function(self, str, a, b)
+    local dictionary, configs
+    if with_dict then dictionary, configs = a, b else configs = a end
+    local ok, err = IsValidArguments(str, with_dict, dictionary, is_compress, configs)
+    if not ok then error(("Usage: LibDeflate:%s(%s): "):format(name, sig) .. err, 2) end
+    if is_compress then return compress(str, fmt, dictionary, configs) end
+    return decompress(str, fmt, dictionary)
+  end
+end
+wrap("CompressDeflate", "str, configs", 0, false, true)
+wrap("CompressDeflateWithDict", "str, dictionary, configs", 0, true, true)
+wrap("CompressZlib", "str, configs", 1, false, true)
+wrap("CompressZlibWithDict", "str, dictionary, configs", 1, true, true)
+wrap("DecompressDeflate", "str", 0, false, false)
+wrap("DecompressDeflateWithDict", "str, dictionary", 0, true, false)
+wrap("DecompressZlib", "str", 1, false, false)
+wrap("DecompressZlibWithDict", "str, dictionary", 1, true, false)
+
+function LibDeflate:EncodeForPrint(str)
+  if type(str) ~= "string" then
+    error(("Usage: LibDeflate:EncodeForPrint(str): 'str' - string expected got '%s'."):format(type(str)), 2)
+  end
+  local cap = math.floor((#str * 8 + 5) / 6) + 16
+  local out, ol = ffi.new("uint8_t[?]", cap), ffi.new("size_t[1]")
+  check(C.ldh_print6_encode(str, #str, out, cap, ol))
+  return ffi.string(out, ol[0])
+end
+function LibDeflate:DecodeForPrint(str)
+  if type(str) ~= "string" then
+    error(("Usage: LibDeflate:DecodeForPrint(str): 'str' - string expected got '%s'."):format(type(str)), 2)
+  end
+  local cap = #str + 16
+  local out, ol, ok = ffi.new("uint8_t[?]", cap), ffi.new("size_t[1]"), ffi.new("int[1]")
+  check(C.ldh_print6_decode(str, #str, out, cap, ol, ok))
+  if ok[0] == 0 then return nil end
+  return ffi.string(out, ol[0])
+end
+
+-- Batched entry point (second return value of require): list of strings in, list of results out.
+local Batch = {}
+function Batch.Compress(strings, fmt, configs, dictionary)
+  local n = #strings
+  local level, strategy = -1, 0
+  if configs then level = configs.level or -1; strategy = STRATEGY[configs.strategy] or 0 end
+  local off = ffi.new("uint64_t[?]", n + 1)
+  local maxlen = 0
+  for i = 1, n do off[i] = off[i - 1] + #strings[i]; maxlen = math.max(maxlen, #strings[i]) end
+  local data = table.concat(strings)
+  local stride = tonumber(C.ldh_compress_bound(maxlen))
+  local out = ffi.new("uint8_t[?]", n * stride)
+  local ol, pb = ffi.new("uint32_t[?]", n), ffi.new("uint8_t[?]", n)
+  check(C.ldh_compress_batch(data, off, n, fmt or 0, level, strategy, handle_of(dictionary), out, stride, ol, pb))
+  local res, pads = {}, {}
+  for i = 1, n do res[i] = ffi.string(out + (i - 1) * stride, ol[i - 1]); pads[i] = pb[i - 1] end
+  return res, pads
+end
+LibDeflate.internals = {IsValidDictionary = IsValidDictionary}
+return LibDeflate, Batch
