@@ -32,6 +32,7 @@ __device__ inline uint32_t trigram(const uint8_t *V, uint32_t v) {
 // ------------------------------------------------------------------ k_sort_links
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
+constexpr int kSortItems = 4;  // elements per thread per tile
 
 // exclusive scan of 256 values held by threads 0..255 (one value each); result in out[256]
 __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *out, uint32_t *wave_tot) {
@@ -54,11 +55,19 @@ __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *o
   __syncthreads();
 }
 
+// V_LDS: the whole virtual buffer also lives in LDS (streams up to kSortLdsMaxV bytes), so
+// the per-element key fetches of passes 1-2 and the trigram compares of the link pass are
+// LDS byte reads instead of fully divergent global loads (which bound the first version).
+constexpr uint32_t kSortLdsMaxV = 131072 + 64;
+
+template <bool V_LDS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
+  extern __shared__ uint8_t ldsV[];
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_base[256];
-  __shared__ uint32_t s_cnt[kSortWaves][256];
-  __shared__ uint32_t s_off[kSortWaves][256];
+  __shared__ uint32_t s_bprev[256];
+  __shared__ uint16_t s_cnt[kSortWaves][256];
+  __shared__ uint16_t s_pre[kSortWaves][256];
   __shared__ uint32_t s_tot[4];
 
   const uint32_t s = blockIdx.x;
@@ -69,6 +78,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   uint32_t *bufA = B.bufA + (size_t)s * B.nvp;
   uint32_t *bufB = B.bufB + (size_t)s * B.nvp;
   uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+#define VBYTE(i) (V_LDS ? (uint32_t)ldsV[(i)] : (uint32_t)V[(i)])
 
   if (tid < 256) s_hist[tid] = 0;
   for (uint32_t i = tid; i < kSortWaves * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
@@ -89,6 +99,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
       word |= byte << (8 * k);
     }
     *(uint32_t *)(V + w) = word;
+    if (V_LDS) *(uint32_t *)(ldsV + w) = word;
   }
   __syncthreads();
   if (nv == 0) return;
@@ -102,46 +113,63 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
       if (tid < 256) {
         const uint32_t m = shift < nv ? shift : nv;
         cnt = s_hist[tid];
-        for (uint32_t j = 0; j < m; j++) cnt -= ((uint32_t)V[j] == tid);
+        for (uint32_t j = 0; j < m; j++) cnt -= (VBYTE(j) == tid);
         if (tid == 0) cnt += m;
       }
       scan256_exclusive(cnt, tid, s_base, s_tot);
     }
 
-    const uint32_t ntiles = (nv + kSortThreads - 1) / kSortThreads;
+    // A tile is kSortItems*1024 consecutive elements; wave w owns 64*kSortItems consecutive
+    // ones of them, so (wave, sub-round, lane) order is element order and ranks stay stable.
+    constexpr uint32_t kTileElems = kSortThreads * kSortItems;
+    const uint32_t ntiles = (nv + kTileElems - 1) / kTileElems;
     for (uint32_t tile = 0; tile < ntiles; tile++) {
-      const uint32_t idx = tile * kSortThreads + tid;
-      const bool valid = idx < nv;
-      uint32_t e = 0, d = 0;
-      if (valid) {
-        e = pass == 0 ? idx : src[idx];
-        d = V[e + shift];
-      }
-      // lanes of this wave holding the same digit (stable rank = lanes below me)
-      unsigned long long mask = __ballot(valid);
+      const uint32_t base_idx = tile * kTileElems + wave * (64 * kSortItems) + lane;
+      uint32_t e[kSortItems], d[kSortItems], lrank[kSortItems];
 #pragma unroll
-      for (int bit = 0; bit < 8; bit++) {
-        unsigned long long bal = __ballot(valid && ((d >> bit) & 1));
-        mask &= ((d >> bit) & 1) ? bal : ~bal;
+      for (int j = 0; j < kSortItems; j++) {
+        const uint32_t idx = base_idx + j * 64;
+        e[j] = idx < nv ? (pass == 0 ? idx : src[idx]) : 0xFFFFFFFFu;
       }
-      const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-      if (valid && rank == 0) s_cnt[wave][d] = __popcll(mask);
+#pragma unroll
+      for (int j = 0; j < kSortItems; j++) d[j] = e[j] != 0xFFFFFFFFu ? VBYTE(e[j] + shift) : 0;
+#pragma unroll
+      for (int j = 0; j < kSortItems; j++) {
+        const bool valid = e[j] != 0xFFFFFFFFu;
+        // lanes of this wave holding the same digit (stable rank = lanes below me)
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+          unsigned long long bal = __ballot(valid && ((d[j] >> bit) & 1));
+          mask &= ((d[j] >> bit) & 1) ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t old = s_cnt[wave][d[j]];  // same digit in this wave's earlier sub-rounds
+        lrank[j] = old + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) s_cnt[wave][d[j]] = (uint16_t)(old + (uint32_t)__popcll(mask));
+        __builtin_amdgcn_wave_barrier();
+      }
       __syncthreads();
-      if (tid < 256) {  // per digit: running offsets over the waves; leaves s_cnt zeroed
-        uint32_t off = s_base[tid];
+      if (tid < 256) {  // per digit: prefix over the waves; leaves s_cnt zeroed
+        const uint32_t off0 = s_base[tid];
+        uint32_t run = 0;
 #pragma unroll
         for (int w = 0; w < kSortWaves; w++) {
-          uint32_t t = s_cnt[w][tid];
+          const uint32_t t = s_cnt[w][tid];
           s_cnt[w][tid] = 0;
-          s_off[w][tid] = off;
-          off += t;
+          s_pre[w][tid] = (uint16_t)run;
+          run += t;
         }
-        s_base[tid] = off;
+        s_bprev[tid] = off0;
+        s_base[tid] = off0 + run;
       }
       __syncthreads();
-      if (valid) dst[s_off[wave][d] + rank] = e;
-      // next tile: s_cnt writes do not alias s_off; the barrier after them orders the
-      // s_off reads above before the next rewrite of s_off.
+#pragma unroll
+      for (int j = 0; j < kSortItems; j++)
+        if (e[j] != 0xFFFFFFFFu) dst[s_bprev[d[j]] + s_pre[wave][d[j]] + lrank[j]] = e[j];
+      // next tile: its s_cnt updates alias neither s_pre nor s_bprev; the barrier after them
+      // orders the reads above before the next rewrite.
     }
     __syncthreads();
   }
@@ -152,36 +180,50 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     uint32_t dlt = 0;
     if (r > 0) {
       uint32_t u = bufA[r - 1];
-      if (trigram(V, u) == trigram(V, v)) {
+      const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
+      const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
+      if (tu == tv) {
         uint32_t d = v - u;
         if (d <= kWindow) dlt = d;
       }
     }
     prevd[v] = (uint16_t)dlt;
   }
+#undef VBYTE
 }
 
 // ------------------------------------------------------------------ k_match_lazy
-constexpr uint32_t kTile = 4096;
+constexpr uint32_t kTile = 8192;
 constexpr int kMatchThreads = 1024;
 constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
 constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
 constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
+constexpr uint32_t kRefillIdle = 16;  // lanes that must be idle before the wave fetches new positions
 
 __device__ inline uint32_t lds_load4(const uint32_t *w, uint32_t byteoff) {
   uint32_t i = byteoff >> 2;
   return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
 }
+__device__ inline uint64_t lds_load8(const uint32_t *w, uint32_t byteoff) {
+  const uint32_t i = byteoff >> 2, sh = byteoff & 3;
+  const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+  return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
+}
 
+// One lane works on one position at a time and walks its chain one candidate per loop
+// trip; lanes whose chain has ended take the next position of the tile from a workgroup
+// counter (chains are 0..max_chain long, so a static position->lane map idles most lanes).
+template <bool HAS_DICT>
 __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t tiles_per_stream) {
   extern __shared__ uint32_t smem[];
-  uint32_t *lbytes = smem;                                       // kLdsByteCap bytes
-  uint16_t *lprev = (uint16_t *)(smem + kLdsByteCap / 4);        // kLdsPrevCap entries
+  uint32_t *lbytes = smem;                                 // kLdsByteCap bytes
+  uint16_t *lprev = (uint16_t *)(smem + kLdsByteCap / 4);  // kLdsPrevCap entries
+  __shared__ uint32_t s_next;
 
   const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t s = work / tiles_per_stream, tile = work % tiles_per_stream;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t n = stream_len(B, s), D = B.dlen;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t n = stream_len(B, s), D = HAS_DICT ? B.dlen : 0;
   const uint32_t q0 = tile * kTile;
   if (q0 >= n) return;
   const uint32_t q1 = (q0 + kTile < n) ? q0 + kTile : n;  // stream positions [q0, q1) 0-based
@@ -189,6 +231,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   const uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
   uint32_t *mout = B.bufB + (size_t)s * B.nvp;
   const LevelCfg cfg = level_cfg(B.level);
+  const uint32_t nice = (uint32_t)cfg.nice;
 
   const uint32_t v0 = q0 + D, v1 = q1 + D;
   const uint32_t wbase = (v0 > kWindow ? v0 - kWindow : 0) & ~3u;
@@ -202,65 +245,87 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     const uint32_t *psrc = (const uint32_t *)(prevd + wbase);
     uint32_t *pdst = (uint32_t *)lprev;
     for (uint32_t i = tid; i < np; i += kMatchThreads) pdst[i] = psrc[i];
+    if (tid == 0) s_next = q0;
   }
   __syncthreads();
 
-  for (uint32_t q = q0 + tid; q < q1; q += kMatchThreads) {
-    const uint32_t p = q + 1;
-    const uint32_t blk = p <= kFirstBlock ? 0u : 1u + (p - kFirstBlock - 1) / kNextBlock;
-    const uint32_t be = block_end(blk, n);
-    uint32_t best = 0, bdist = 0;
-    if (p + 2 <= be) {  // LD:1349
-      const uint32_t v = q + D;
-      uint32_t maxlen = be - p + 1;
-      if (maxlen > kMaxMatch) maxlen = kMaxMatch;
-      const uint32_t t0w = lds_load4(lbytes, v + 3 - wbase);
-      const uint32_t t1w = lds_load4(lbytes, v + 7 - wbase);
-      uint32_t c = v;
-      int depth = cfg.max_chain;  // Q3
-      bool seen_seed = false;
-      while (depth > 0) {
-        const uint32_t d = lprev[c - wbase];
-        if (d == 0) break;
-        c -= d;
-        if (v - c > kWindow) break;  // LD:1365
-        if (c < D) {                 // dictionary side of V (Q10)
-          if (c + 2 < D) {           // LibDeflate position <= -2: dictionary chain entry
-            if (seen_seed) break;    // LD:1394: no fall-through after a seed (-1 / 0)
+  bool active = false, exhausted = false, seen_seed = false;
+  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0;
+  int depth = 0;
+  uint64_t tw = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    if (!exhausted && (nidle >= kRefillIdle)) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_next, nidle);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!active) {
+        const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (my < q1) {
+          const uint32_t p = my + 1;
+          const uint32_t blk = p <= kFirstBlock ? 0u : 1u + (p - kFirstBlock - 1) / kNextBlock;
+          const uint32_t be = block_end(blk, n);
+          if (p + 2 <= be) {  // LD:1349
+            q = my;
+            vb = my + D - wbase;
+            cb = vb;
+            maxlen = be - p + 1;
+            if (maxlen > kMaxMatch) maxlen = kMaxMatch;
+            tw = lds_load8(lbytes, vb + 3);
+            depth = cfg.max_chain;  // Q3
+            best = 0;
+            seen_seed = false;
+            active = true;
+          } else {
+            mout[my] = 0;
+          }
+        }
+      }
+      if (base + nidle >= q1) exhausted = true;
+      continue;
+    }
+    if (nidle == 64) break;
+    if (active) {
+      const uint32_t d = lprev[cb];
+      cb -= d;
+      bool stop = (d == 0) | (vb - cb > kWindow);  // chain end / LD:1365
+      if (HAS_DICT) {                              // dictionary side of V (Q10)
+        const uint32_t c = cb + wbase;
+        if (!stop && c < D) {
+          if (c + 2 < D) {          // LibDeflate position <= -2: dictionary chain entry
+            stop = seen_seed;       // LD:1394: no fall-through after a seed (-1 / 0)
           } else {
             seen_seed = true;
           }
         }
-        uint32_t L;
-        uint32_t x = lds_load4(lbytes, c + 3 - wbase) ^ t0w;
-        if (x) {
-          L = 3 + (__builtin_ctz(x) >> 3);
-        } else {
-          x = lds_load4(lbytes, c + 7 - wbase) ^ t1w;
-          if (x) {
-            L = 7 + (__builtin_ctz(x) >> 3);
-          } else {
-            L = 11;
-            while (L < maxlen) {
-              x = lds_load4(lbytes, c + L - wbase) ^ lds_load4(lbytes, v + L - wbase);
-              if (x) {
-                L += __builtin_ctz(x) >> 3;
-                break;
-              }
-              L += 4;
+      }
+      if (!stop) {
+        const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
+        uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
+        if (x == 0) {
+          while (L < maxlen) {
+            const uint32_t y = lds_load4(lbytes, cb + L) ^ lds_load4(lbytes, vb + L);
+            if (y) {
+              L += __builtin_ctz(y) >> 3;
+              break;
             }
+            L += 4;
           }
         }
         if (L > maxlen) L = maxlen;
         if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
           best = L;
-          bdist = v - c;
+          bdist = vb - cb;
         }
-        if (best >= (uint32_t)cfg.nice) break;  // LD:1389
         depth--;
+        stop = (best >= nice) | (depth == 0);  // LD:1389, LD:1362
+      }
+      if (stop) {
+        mout[q] = best ? ((best << 16) | bdist) : 0u;
+        active = false;
       }
     }
-    mout[q] = best ? ((best << 16) | bdist) : 0u;
   }
 }
 

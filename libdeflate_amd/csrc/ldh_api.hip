@@ -202,7 +202,11 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   if (int rc = ensure(g_adler, chunk * 4 + 64)) return rc;
 
   if (!g_attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(kSortLdsMaxV)));
+    HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)kMatchLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)kMatchLdsBytes));
     g_attr_done = true;
   }
@@ -245,13 +249,18 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
     }
     // V (and, for the match search, the trigram chains)
-    LAUNCH("k_sort_links", k_sort_links, c, kSortThreads, 0, B);  // TODO(round 2): skip the sort for level 0 / huffman_only
+    // TODO(round 2): skip the sort for level 0 / huffman_only (only V is needed there)
+    if ((size_t)nvp + kVPad <= kSortLdsMaxV)
+      LAUNCH("k_sort_links", k_sort_links<true>, c, kSortThreads, (nvp + kVPad + 15) & ~15u, B);
+    else
+      LAUNCH("k_sort_links", k_sort_links<false>, c, kSortThreads, 0, B);
     if (level != 0) {
       if (strategy == LDH_STRATEGY_HUFFMAN_ONLY) {
         LAUNCH("k_tokens_literal", k_tokens_literal, c, 256, 0, B);
       } else if (level_cfg(level).lazy) {
         const uint32_t tiles = (uint32_t)((max_in_len + kTile - 1) / kTile);
-        if (tiles) LAUNCH("k_match_lazy", k_match_lazy, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        if (tiles && vd) LAUNCH("k_match_lazy", k_match_lazy<true>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        if (tiles && !vd) LAUNCH("k_match_lazy", k_match_lazy<false>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
         const uint32_t units = c * max_blocks;
         LAUNCH("k_parse_lazy", k_parse_lazy, (units + 63) / 64, 64, 0, B);
       } else {
