@@ -249,23 +249,36 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   }
   __syncthreads();
 
-  bool active = false, exhausted = false, seen_seed = false;
-  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0;
-  int depth = 0;
+  // a tile (8192 positions) straddles at most one deflate-block end
+  const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
+  const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
+  const uint8_t *lb8 = (const uint8_t *)lbytes;
+  const uint32_t refill_idle = B.tune[0] ? B.tune[0] : kRefillIdle;
+
+  // The scalar unit (exec-mask bookkeeping of divergent branches) bounds this loop, so the
+  // chain step is written predicated; only the full compare is a divergent branch, the
+  // refill check runs once per kStepsPerCheck steps and results are stored at refill time.
+  constexpr int kStepsPerCheck = 4;
+  bool active = false, pending = false, exhausted = false, seen_seed = false;
+  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, tbyte = 0;
+  uint32_t depth = 0;
   uint64_t tw = 0;
   for (;;) {
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (!exhausted && (nidle >= kRefillIdle)) {
+    if (!exhausted && (nidle >= refill_idle)) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&s_next, nidle);
       base = __builtin_amdgcn_readfirstlane(base);
       if (!active) {
+        if (pending) {
+          mout[q] = best ? ((best << 16) | bdist) : 0u;
+          pending = false;
+        }
         const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (my < q1) {
           const uint32_t p = my + 1;
-          const uint32_t blk = p <= kFirstBlock ? 0u : 1u + (p - kFirstBlock - 1) / kNextBlock;
-          const uint32_t be = block_end(blk, n);
+          const uint32_t be = p <= be_lo ? be_lo : be_hi;
           if (p + 2 <= be) {  // LD:1349
             q = my;
             vb = my + D - wbase;
@@ -273,10 +286,12 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
             maxlen = be - p + 1;
             if (maxlen > kMaxMatch) maxlen = kMaxMatch;
             tw = lds_load8(lbytes, vb + 3);
-            depth = cfg.max_chain;  // Q3
+            tbyte = lb8[vb];
+            depth = (uint32_t)cfg.max_chain;  // Q3
             best = 0;
             seen_seed = false;
             active = true;
+            pending = true;
           } else {
             mout[my] = 0;
           }
@@ -286,26 +301,26 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       continue;
     }
     if (nidle == 64) break;
-    if (active) {
+#pragma unroll
+    for (int step = 0; step < kStepsPerCheck; step++) {
       const uint32_t d = lprev[cb];
-      cb -= d;
-      bool stop = (d == 0) | (vb - cb > kWindow);  // chain end / LD:1365
-      if (HAS_DICT) {                              // dictionary side of V (Q10)
-        const uint32_t c = cb + wbase;
-        if (!stop && c < D) {
-          if (c + 2 < D) {          // LibDeflate position <= -2: dictionary chain entry
-            stop = seen_seed;       // LD:1394: no fall-through after a seed (-1 / 0)
-          } else {
-            seen_seed = true;
-          }
-        }
+      const uint32_t cbn = cb - d;
+      bool go = active & (d != 0) & (vb - cbn <= kWindow);  // chain end / LD:1365
+      if (HAS_DICT) {                                       // dictionary side of V (Q10)
+        const uint32_t c = cbn + wbase;
+        const bool in_dict = c < D, deep = c + 2 < D;
+        go = go & !(in_dict & deep & seen_seed);  // LD:1394: no fall-through after a seed (-1 / 0)
+        seen_seed = seen_seed | (go & in_dict & !deep);
       }
-      if (!stop) {
-        const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
+      // A candidate can only beat `best` if it also matches at offset `best` (the trigram
+      // makes offsets 0..2 equal): one byte read rejects most candidates.
+      const uint32_t cbs = go ? cbn : vb;
+      if (go & (lb8[cbs + best] == tbyte)) {
+        const uint64_t x = lds_load8(lbytes, cbn + 3) ^ tw;
         uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
         if (x == 0) {
           while (L < maxlen) {
-            const uint32_t y = lds_load4(lbytes, cb + L) ^ lds_load4(lbytes, vb + L);
+            const uint32_t y = lds_load4(lbytes, cbn + L) ^ lds_load4(lbytes, vb + L);
             if (y) {
               L += __builtin_ctz(y) >> 3;
               break;
@@ -316,17 +331,18 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
         if (L > maxlen) L = maxlen;
         if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
           best = L;
-          bdist = vb - cb;
+          bdist = vb - cbn;
+          tbyte = lb8[vb + best];
         }
-        depth--;
-        stop = (best >= nice) | (depth == 0);  // LD:1389, LD:1362
       }
-      if (stop) {
-        mout[q] = best ? ((best << 16) | bdist) : 0u;
-        active = false;
-      }
+      depth -= go ? 1u : 0u;
+      cb = go ? cbn : cb;
+      // LD:1389 nice_length, LD:1362 depth; a match of maxlen cannot be beaten (the walk has
+      // no side effects, so ending it early leaves the result unchanged)
+      active = go & (best < nice) & (depth != 0) & (best < maxlen);
     }
   }
+  if (pending) mout[q] = best ? ((best << 16) | bdist) : 0u;
 }
 
 // ------------------------------------------------------------------ k_parse_lazy

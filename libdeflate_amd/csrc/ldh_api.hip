@@ -226,6 +226,12 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.level = level;
     B.strategy = strategy;
     B.fmt = fmt;
+    for (int t = 0; t < 4; t++) {
+      char nm[16];
+      snprintf(nm, sizeof(nm), "LDH_TUNE%d", t);
+      const char *ev = getenv(nm);
+      B.tune[t] = ev ? (uint32_t)strtoul(ev, nullptr, 10) : 0;
+    }
     B.vbuf = (uint8_t *)g_vbuf.p;
     B.prevd = (uint16_t *)g_prevd.p;
     B.bufA = (uint32_t *)g_bufA.p;

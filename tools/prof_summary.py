@@ -3,6 +3,8 @@
 small CSV (what gets committed under profiles/)."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    r["Name"] = r["Name"].replace("void ldh::", "ldh::")
 tot = sum(int(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("ldh::"))
 print("kernel,calls,total_ms,avg_ms,share_of_ldh_pct,min_ms,max_ms")
 for r in rows:
