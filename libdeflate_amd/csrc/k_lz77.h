@@ -258,12 +258,62 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   // The scalar unit (exec-mask bookkeeping of divergent branches) bounds this loop, so the
   // chain step is written predicated; only the full compare is a divergent branch, the
   // refill check runs once per kStepsPerCheck steps and results are stored at refill time.
-  constexpr int kStepsPerCheck = 4;
-  bool active = false, pending = false, exhausted = false, seen_seed = false;
-  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, tbyte = 0;
+  // Lane states: idle (waits for the next refill), walking (`active`), or holding a candidate
+  // that passed the 2-byte quick reject and waits for the batched full compare (`cmpp`).
+  // The VALU is the bound (4 cycles per wave64 op), so the rare long paths -- refill and
+  // full compare -- run once per round for all lanes that need them instead of per step.
+  constexpr uint32_t steps_per_round = 8;
+  bool active = false, cmpp = false, pending = false, exhausted = false, seen_seed = false;
+  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, t2 = 0, dsave = 0;
   uint32_t depth = 0;
   uint64_t tw = 0;
+
+  // next hop after candidate `cb` was evaluated: LD:1389 nice_length, LD:1362 depth, chain
+  // end, LD:1365 window; a match of maxlen cannot be beaten (the walk has no side effects, so
+  // ending it early leaves the result unchanged)
+#define LDH_ADVANCE(cond, dn_)                                                                   \
+  {                                                                                              \
+    depth -= (cond) ? 1u : 0u;                                                                   \
+    const uint32_t cn_ = cb - (dn_);                                                             \
+    bool go_ = (cond) & (best < nice) & (depth != 0) & (best < maxlen) & ((dn_) != 0) &          \
+               (vb - cn_ <= kWindow);                                                            \
+    if (HAS_DICT) { /* dictionary side of V (Q10) */                                             \
+      const uint32_t c_ = cn_ + wbase;                                                           \
+      const bool in_dict_ = c_ < D, deep_ = c_ + 2 < D;                                          \
+      go_ = go_ & !(in_dict_ & deep_ & seen_seed); /* LD:1394: no fall-through after a seed */   \
+      seen_seed = seen_seed | (go_ & in_dict_ & !deep_);                                         \
+    }                                                                                            \
+    cb = go_ ? cn_ : cb;                                                                         \
+    active = (cond) ? go_ : active;                                                              \
+  }
+
   for (;;) {
+    // ---- batched full compare of the candidates that passed the quick reject
+    if (__ballot(cmpp)) {
+      if (cmpp) {
+        const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
+        uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
+        if (x == 0) {
+          while (L < maxlen) {
+            const uint32_t y = lds_load4(lbytes, cb + L) ^ lds_load4(lbytes, vb + L);
+            if (y) {
+              L += __builtin_ctz(y) >> 3;
+              break;
+            }
+            L += 4;
+          }
+        }
+        if (L > maxlen) L = maxlen;
+        if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
+          best = L;
+          bdist = vb - cb;
+          t2 = (uint32_t)lb8[vb + best - 1] | ((uint32_t)lb8[vb + best] << 8);
+        }
+        LDH_ADVANCE(true, dsave);
+        cmpp = false;
+      }
+    }
+    // ---- refill idle lanes
     const unsigned long long idle = __ballot(!active);
     const uint32_t nidle = (uint32_t)__popcll(idle);
     if (!exhausted && (nidle >= refill_idle)) {
@@ -282,15 +332,17 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
           if (p + 2 <= be) {  // LD:1349
             q = my;
             vb = my + D - wbase;
-            cb = vb;
+            const uint32_t d0 = lprev[vb];
+            cb = vb - d0;
             maxlen = be - p + 1;
             if (maxlen > kMaxMatch) maxlen = kMaxMatch;
             tw = lds_load8(lbytes, vb + 3);
-            tbyte = lb8[vb];
+            t2 = (uint32_t)lb8[vb] | ((uint32_t)lb8[vb + 1] << 8);
             depth = (uint32_t)cfg.max_chain;  // Q3
             best = 0;
-            seen_seed = false;
-            active = true;
+            bdist = 0;
+            active = (d0 != 0) & (d0 <= kWindow);  // chain empty / LD:1365
+            seen_seed = HAS_DICT && active && (cb + wbase < D) && !(cb + wbase + 2 < D);
             pending = true;
           } else {
             mout[my] = 0;
@@ -301,47 +353,23 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       continue;
     }
     if (nidle == 64) break;
+    // ---- chain steps: one LDS round trip each (link of the candidate + its reject bytes)
 #pragma unroll
-    for (int step = 0; step < kStepsPerCheck; step++) {
-      const uint32_t d = lprev[cb];
-      const uint32_t cbn = cb - d;
-      bool go = active & (d != 0) & (vb - cbn <= kWindow);  // chain end / LD:1365
-      if (HAS_DICT) {                                       // dictionary side of V (Q10)
-        const uint32_t c = cbn + wbase;
-        const bool in_dict = c < D, deep = c + 2 < D;
-        go = go & !(in_dict & deep & seen_seed);  // LD:1394: no fall-through after a seed (-1 / 0)
-        seen_seed = seen_seed | (go & in_dict & !deep);
-      }
-      // A candidate can only beat `best` if it also matches at offset `best` (the trigram
-      // makes offsets 0..2 equal): one byte read rejects most candidates.
-      const uint32_t cbs = go ? cbn : vb;
-      if (go & (lb8[cbs + best] == tbyte)) {
-        const uint64_t x = lds_load8(lbytes, cbn + 3) ^ tw;
-        uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
-        if (x == 0) {
-          while (L < maxlen) {
-            const uint32_t y = lds_load4(lbytes, cbn + L) ^ lds_load4(lbytes, vb + L);
-            if (y) {
-              L += __builtin_ctz(y) >> 3;
-              break;
-            }
-            L += 4;
-          }
-        }
-        if (L > maxlen) L = maxlen;
-        if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
-          best = L;
-          bdist = vb - cbn;
-          tbyte = lb8[vb + best];
-        }
-      }
-      depth -= go ? 1u : 0u;
-      cb = go ? cbn : cb;
-      // LD:1389 nice_length, LD:1362 depth; a match of maxlen cannot be beaten (the walk has
-      // no side effects, so ending it early leaves the result unchanged)
-      active = go & (best < nice) & (depth != 0) & (best < maxlen);
+    for (uint32_t step = 0; step < steps_per_round; step++) {
+      const bool run = active & !cmpp;
+      const uint32_t cs = run ? cb : vb;
+      const uint32_t dn = lprev[cs];
+      // A candidate can only beat `best` if it also matches at offsets best-1 and best (the
+      // trigram makes offsets 0..2 equal): two byte reads reject nearly every candidate.
+      const uint32_t o = cs + (best ? best - 1 : 0);
+      const uint32_t q2 = (uint32_t)lb8[o] | ((uint32_t)lb8[o + 1] << 8);
+      const bool pass = run & (q2 == t2);
+      cmpp = cmpp | pass;
+      dsave = pass ? dn : dsave;
+      LDH_ADVANCE(run & !pass, dn);
     }
   }
+#undef LDH_ADVANCE
   if (pending) mout[q] = best ? ((best << 16) | bdist) : 0u;
 }
 
