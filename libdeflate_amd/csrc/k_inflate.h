@@ -220,72 +220,212 @@ struct OutState {
   uint8_t *out;
   uint64_t cap;
   uint64_t opos;     // bytes produced
-  uint32_t bufsz;    // the reference's buffer_size (LD:2432-2439): opos minus flushed 32 KiB pages
   const uint8_t *dict;
   uint32_t dlen;
   bool dict_loaded;  // buffer[0] ~= nil (LD:2367)
 };
 
-// DecodeUntilEndOfBlock (LD:2353-2445)
-__device__ int decode_block(const DecTab &LT, const DecTab &DT, int lbits, int dbits, BitReader &R,
-                            OutState &O, uint32_t lane) {
+// One token of DecodeUntilEndOfBlock (LD:2379-2440), wave-uniform ("scalar") form.  Used for
+// tokens the lane-parallel decoder cannot resolve (codes longer than the lookup table, invalid
+// codes).  *eob is set when the token was the end-of-block symbol.
+// The reference's buffer_size only differs from the output position after it reached 65536,
+// where no distance (<= 32768) can fail, so `dist > opos + ext` is the -11 test (LD:2406-2410).
+__device__ int decode_one(const DecTab &LT, const DecTab &DT, int lbits, int dbits, BitReader &R,
+                          OutState &O, uint32_t ext, uint32_t lane, bool *eob) {
+  const int symbol = decode_sym(LT, lbits, R, lane);
+  *eob = symbol == 256;
+  if (symbol < 0 || symbol > 285) return -10;
+  if (symbol < 256) {
+    if (O.opos >= O.cap) return kStatusOutputFull;
+    if (lane == 0) O.out[O.opos] = (uint8_t)symbol;
+    O.opos++;
+  } else if (symbol > 256) {
+    const uint32_t ls = (uint32_t)symbol - 257;
+    uint32_t len;  // LD:188-200 base lengths, computed instead of tabulated
+    if (ls < 8) {
+      len = 3 + ls;
+    } else if (ls == 28) {
+      len = 258;
+    } else {
+      const uint32_t eb = (ls >> 2) - 1;
+      len = 3 + ((4u + (ls & 3)) << eb) + br_read(R, eb, lane);
+    }
+    const int dsym = decode_sym(DT, dbits, R, lane);
+    if (dsym < 0 || dsym > 29) return -10;
+    uint32_t dist;
+    if (dsym < 4) {
+      dist = (uint32_t)dsym + 1;
+    } else {
+      const uint32_t eb = dist_extra_bits((uint32_t)dsym);
+      dist = 1 + ((2u + ((uint32_t)dsym & 1)) << eb) + br_read(R, eb, lane);
+    }
+    if ((uint64_t)dist > O.opos + ext) return -11;
+    if (O.opos + len > O.cap) return kStatusOutputFull;
+    // bytes this wave stored earlier must be visible to the loads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int64_t src0 = (int64_t)O.opos - (int64_t)dist;
+    for (uint32_t k = lane; k < len; k += kWave) {
+      const uint32_t j = dist >= len ? k : (k % dist);
+      const int64_t si = src0 + j;
+      const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+      O.out[O.opos + k] = byte;
+    }
+    O.opos += len;
+  }
+  if (br_left(R) < 0) return 2;  // LD:2428
+  return 0;
+}
+
+__device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lane) {
+  br_seek(R, bit_pos >> 3, lane);
+  const uint32_t drop = (uint32_t)(bit_pos & 7);
+  R.bitbuf >>= drop;
+  R.bitcnt -= drop;
+  R.consumed = bit_pos;
+}
+
+// DecodeUntilEndOfBlock (LD:2353-2445), lane-parallel.
+// The scalar unit, not the vector lanes, bounded the wave-uniform decoder (every branch and
+// every uniform bit operation is a scalar instruction, one per cycle per CU).  Here lane k
+// decodes, speculatively, the token that would start k bits after the current position
+// (table lookups are per-lane LDS gathers); walking next[k] = k + token_bits from lane 0
+// then picks the real tokens of this 64-bit window (about six per round).  Literals are
+// stored by their lanes at once; matches are copied one after the other by the whole wave.
+// Tokens the tables cannot resolve fall back to decode_one.
+__device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
+                            uint32_t *s_in /* LDS, 64 dwords */) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
     ext = O.dlen;
     O.dict_loaded = true;
   }
+  const uint64_t nbits = (uint64_t)R.nbytes * 8;
+  const uint64_t skip_bits = (uint64_t)R.skip * 8;
+  uint64_t bp = R.consumed;        // bits consumed so far (uniform)
+  uint32_t cw0 = 0xFFFFFFFFu;      // first dword (relative to R.base) held in s_in
   for (;;) {
-    const int symbol = decode_sym(LT, lbits, R, lane);
-    if (symbol < 0 || symbol > 285) return -10;
-    if (symbol < 256) {
-      if (O.opos >= O.cap) return kStatusOutputFull;
-      if (lane == 0) O.out[O.opos] = (uint8_t)symbol;
-      O.opos++;
-      O.bufsz++;
-    } else if (symbol > 256) {
-      const uint32_t ls = (uint32_t)symbol - 257;
-      uint32_t len;  // LD:188-200 base lengths, computed instead of tabulated
-      if (ls < 8) {
-        len = 3 + ls;
-      } else if (ls == 28) {
-        len = 258;
-      } else {
-        const uint32_t eb = (ls >> 2) - 1;
-        len = 3 + ((4u + (ls & 3)) << eb) + br_read(R, eb, lane);
+    const uint64_t absbit = skip_bits + bp;
+    const uint32_t dw = (uint32_t)(absbit >> 5);
+    if (cw0 == 0xFFFFFFFFu || dw < cw0 || dw + 6 >= cw0 + 64) {
+      __syncthreads();
+      cw0 = dw;
+      const uint64_t first = ((uint64_t)cw0 + lane) * 4;
+      const uint64_t end = (uint64_t)R.skip + R.nbytes;
+      uint32_t x = 0;
+      if (first < end) {
+        x = R.base[cw0 + lane];
+        if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
       }
-      const int dsym = decode_sym(DT, dbits, R, lane);
-      if (dsym < 0 || dsym > 29) return -10;
-      uint32_t dist;
-      if (dsym < 4) {
-        dist = (uint32_t)dsym + 1;
-      } else {
-        const uint32_t eb = dist_extra_bits((uint32_t)dsym);
-        dist = 1 + ((2u + ((uint32_t)dsym & 1)) << eb) + br_read(R, eb, lane);
-      }
-      if ((uint64_t)dist > (uint64_t)O.bufsz + ext) return -11;  // LD:2406-2410
-      if (O.opos + len > O.cap) return kStatusOutputFull;
-      // bytes this wave stored earlier must be visible to the loads below
+      s_in[lane] = x;
+      __syncthreads();
+    }
+    // ---- every lane decodes the token starting `lane` bits ahead
+    const uint32_t bit = (uint32_t)(absbit - (uint64_t)cw0 * 32) + lane;
+    const uint32_t di = bit >> 5, sh = bit & 31;
+    const uint32_t w0 = s_in[di], w1 = s_in[di + 1], w2 = s_in[di + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const uint64_t win = ((uint64_t)hi << 32) | lo;
+    const uint32_t e = LT.lut[lo & (kLutSize - 1)];
+    const uint32_t sym = e >> 4, l1 = e & 15;
+    const bool is_lit = sym < 256, is_eob = sym == 256, is_len = sym > 256;
+    bool slow = e == 0;
+    bool bad = sym > 285;
+    const uint32_t ls = is_len ? (sym > 285 ? 28u : sym - 257) : 0u;
+    const uint32_t leb = (ls < 8 || ls == 28) ? 0u : (ls >> 2) - 1;
+    const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4u + (ls & 3)) << leb));
+    const uint32_t mlen = lbase + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
+    const uint32_t t = l1 + leb;
+    const uint32_t din = (uint32_t)(win >> t);
+    const uint32_t e2 = DT.lut[din & (kLutSize - 1)];
+    const uint32_t dsym = e2 >> 4, l2 = e2 & 15;
+    slow = slow | (is_len & (e2 == 0));
+    bad = bad | (is_len & (dsym > 29));
+    const uint32_t dsc = dsym > 29 ? 29u : dsym;
+    const uint32_t deb = dsc < 4 ? 0u : (dsc >> 1) - 1;
+    const uint32_t dbase = dsc < 4 ? dsc + 1 : 1 + ((2u + (dsc & 1)) << deb);
+    const uint32_t dist = dbase + ((din >> l2) & ((1u << deb) - 1u));
+    const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
+    const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
+
+    // ---- walk the chain of real tokens from lane 0; my_off = output offset of each
+    const unsigned long long hard = __ballot(slow | bad | is_eob);  // the walk cannot pass these
+    unsigned long long valid = 0;
+    uint32_t k = 0, run = 0, my_off = 0;
+    while (k < 64) {
+      valid |= 1ull << k;
+      my_off = lane == k ? run : my_off;
+      if ((hard >> k) & 1) break;
+      run += __builtin_amdgcn_readlane(out_len, k);
+      k += __builtin_amdgcn_readlane(tok_bits, k);
+    }
+    const bool is_tok = (valid >> lane) & 1;
+    // ---- stop events, in the reference's order of checks for one token
+    const uint64_t my_pos = O.opos + my_off;
+    const bool err11 = is_len & ((uint64_t)dist > my_pos + ext);            // LD:2406-2410
+    const bool full = my_pos + out_len > O.cap;
+    const bool exh = bp + lane + tok_bits > nbits;                          // LD:2428
+    const unsigned long long stops = __ballot(is_tok & (slow | bad | err11 | full | exh | is_eob));
+    const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
+    const bool commit = is_tok & (lane < first);
+    // ---- literals of this round
+    if (commit & is_lit) O.out[my_pos] = (uint8_t)sym;
+    // ---- matches of this round, in order
+    unsigned long long mm = __ballot(commit & is_len);
+    while (mm) {
+      const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+      mm &= mm - 1;
+      const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+      const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+      const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int64_t src0 = (int64_t)O.opos - (int64_t)dist;
-      for (uint32_t k = lane; k < len; k += kWave) {
-        const uint32_t j = dist >= len ? k : (k % dist);
-        const int64_t si = src0 + j;
+      const int64_t src0 = (int64_t)dst - (int64_t)d;
+      for (uint32_t i = lane; i < len; i += kWave) {
+        const uint32_t jj = d >= len ? i : (i % d);
+        const int64_t si = src0 + jj;
         const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
-        O.out[O.opos + k] = byte;
+        O.out[dst + i] = byte;
       }
-      O.opos += len;
-      O.bufsz += len;
     }
-    if (br_left(R) < 0) return 2;               // LD:2428
-    if (O.bufsz >= 65536) O.bufsz -= 32768;     // LD:2432-2439
-    if (symbol == 256) return 0;
+    if (first == 64) {  // the whole window was consumed
+      O.opos += run;
+      bp += k;
+      continue;
+    }
+    // ---- the stopping token
+    const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
+                        (exh ? 16u : 0u) | (is_eob ? 32u : 0u);
+    const uint32_t f = __builtin_amdgcn_readlane(fl, first);
+    O.opos += __builtin_amdgcn_readlane(my_off, first);
+    bp += first;
+    if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
+      br_seek_bits(R, bp, lane);
+      bool eob = false;
+      const int st = decode_one(LT, DT, kLutBits, kLutBits, R, O, ext, lane, &eob);
+      if (st != 0) return st;
+      if (eob) return 0;
+      bp = R.consumed;
+      continue;
+    }
+    R.consumed = bp;
+    if (f & 2) return -10;
+    if (f & 4) return -11;
+    if (f & 8) return kStatusOutputFull;
+    bp += __builtin_amdgcn_readlane(tok_bits, first);
+    R.consumed = bp;
+    if (f & 16) return 2;
+    // end of block: hand the position back to the wave-uniform reader
+    br_seek_bits(R, bp, lane);
+    return 0;
   }
 }
 
 __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
   __shared__ DecTab LT, DT;
   __shared__ uint8_t lens[320 + 32];
+  __shared__ uint32_t s_in[kWave + 4];
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
   const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
@@ -295,7 +435,6 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
   O.out = A.out + (size_t)s * A.out_stride;
   O.cap = A.out_stride;
   O.opos = 0;
-  O.bufsz = 0;
   O.dict = A.dict;
   O.dlen = A.dlen;
   O.dict_loaded = false;
@@ -337,9 +476,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
         const uint8_t *src = A.in + off + ipos;
         for (uint32_t k = lane; k < len; k += kWave) O.out[O.opos + k] = src[k];
         O.opos += len;
-        O.bufsz += len;
         br_seek(R, ipos + len, lane);
-        if (O.bufsz >= 65536) O.bufsz -= 32768;  // LD:2483-2488
       } else if (type == 1) {  // LD:2496-2501
         if (fixed_ready != 1) {
           for (int i = lane; i < 288; i += kWave) lens[i] = (uint8_t)fixed_lit_bits(i);
@@ -349,7 +486,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
           build_table(DT, lens + 288, 32, 5, kLutBits, lane);
           fixed_ready = 1;
         }
-        status = decode_block(LT, DT, kLutBits, kLutBits, R, O, lane);
+        status = decode_block(LT, DT, R, O, lane, s_in);
       } else if (type == 2) {  // LD:2506-2615
         fixed_ready = 0;
         const uint32_t nlen = br_read(R, 5, lane) + 257;
@@ -407,7 +544,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
         err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
-        status = decode_block(LT, DT, kLutBits, kLutBits, R, O, lane);
+        status = decode_block(LT, DT, R, O, lane, s_in);
       } else {
         status = -1;
       }
