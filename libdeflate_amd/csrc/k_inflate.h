@@ -44,6 +44,7 @@ struct InflateArgs {
   uint32_t *bytes_left;
   int32_t *status;
   uint32_t *expect_adler;  // zlib trailer value per stream (checked by k_zlib_check)
+  uint32_t tune;           // experiment switches (LDH_TUNE_INFLATE), 0 in production
 };
 
 struct BitReader {
@@ -290,11 +291,13 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // every uniform bit operation is a scalar instruction, one per cycle per CU).  Here lane k
 // decodes, speculatively, the token that would start k bits after the current position
 // (table lookups are per-lane LDS gathers); walking next[k] = k + token_bits from lane 0
-// then picks the real tokens of this 64-bit window (about six per round).  Literals are
-// stored by their lanes at once; matches are copied one after the other by the whole wave.
+// then picks the real tokens of this 64-bit window (about eight per round).  Literals are
+// stored by their lanes at once.  A match whose source is older than everything in flight
+// is loaded at once (one lane per byte) and stored a round later, so that the load latency
+// overlaps the next round's decode; matches that read recent output are copied in order.
 // Tokens the tables cannot resolve fall back to decode_one.
 __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
-                            uint32_t *s_in /* LDS, 64 dwords */) {
+                            uint32_t *s_in /* LDS, 64 dwords */, uint32_t tune) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
     ext = O.dlen;
@@ -304,6 +307,10 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
   const uint64_t skip_bits = (uint64_t)R.skip * 8;
   uint64_t bp = R.consumed;        // bits consumed so far (uniform)
   uint32_t cw0 = 0xFFFFFFFFu;      // first dword (relative to R.base) held in s_in
+  // match copies in flight: bytes loaded in one round are stored in the next
+  constexpr int kPend = 4;
+  uint32_t pend_n = 0, pval[kPend] = {0, 0, 0, 0}, plen[kPend] = {0, 0, 0, 0};
+  uint64_t pdst[kPend] = {0, 0, 0, 0};
   for (;;) {
     const uint64_t absbit = skip_bits + bp;
     const uint32_t dw = (uint32_t)(absbit >> 5);
@@ -349,50 +356,106 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
     const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
     const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
 
-    // ---- walk the chain of real tokens from lane 0; my_off = output offset of each
-    const unsigned long long hard = __ballot(slow | bad | is_eob);  // the walk cannot pass these
+    // ---- walk the chain of real tokens from lane 0; my_off = output offset of each.
+    // A token the walk cannot pass (slow / invalid / end of block) advances by 64.
+    const bool hard = slow | bad | is_eob;
+    const uint32_t P = hard ? 64u : (tok_bits | (out_len << 8));
     unsigned long long valid = 0;
     uint32_t k = 0, run = 0, my_off = 0;
-    while (k < 64) {
+    do {
+      const uint32_t p = __builtin_amdgcn_readlane(P, k);
       valid |= 1ull << k;
       my_off = lane == k ? run : my_off;
-      if ((hard >> k) & 1) break;
-      run += __builtin_amdgcn_readlane(out_len, k);
-      k += __builtin_amdgcn_readlane(tok_bits, k);
-    }
+      run += p >> 8;
+      k += p & 0xff;
+    } while (k < 64);
     const bool is_tok = (valid >> lane) & 1;
     // ---- stop events, in the reference's order of checks for one token
     const uint64_t my_pos = O.opos + my_off;
     const bool err11 = is_len & ((uint64_t)dist > my_pos + ext);            // LD:2406-2410
     const bool full = my_pos + out_len > O.cap;
     const bool exh = bp + lane + tok_bits > nbits;                          // LD:2428
-    const unsigned long long stops = __ballot(is_tok & (slow | bad | err11 | full | exh | is_eob));
+    const unsigned long long stops = __ballot(is_tok & (hard | err11 | full | exh));
     const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
     const bool commit = is_tok & (lane < first);
+    // ---- copies deferred by the previous round: their loads have had a whole round to land
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // every store issued before this point is complete: all output below `fenced` is readable
+    const uint64_t fenced = pend_n ? pdst[0] : O.opos;
+#pragma unroll
+    for (int q = 0; q < kPend; q++)
+      if (q < (int)pend_n && lane < plen[q]) O.out[pdst[q] + lane] = (uint8_t)pval[q];
+    pend_n = 0;
     // ---- literals of this round
     if (commit & is_lit) O.out[my_pos] = (uint8_t)sym;
-    // ---- matches of this round, in order
-    unsigned long long mm = __ballot(commit & is_len);
-    while (mm) {
-      const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-      mm &= mm - 1;
-      const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
-      const uint32_t d = __builtin_amdgcn_readlane(dist, j);
-      const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int64_t src0 = (int64_t)dst - (int64_t)d;
-      for (uint32_t i = lane; i < len; i += kWave) {
-        const uint32_t jj = d >= len ? i : (i % d);
-        const int64_t si = src0 + jj;
-        const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
-        O.out[dst + i] = byte;
+    // ---- matches of this round
+    const bool cm = commit & is_len;
+    unsigned long long mm = __ballot(cm);
+    if (mm) {
+      // a match whose source [dst-dist, dst-dist+len) lies wholly below `fenced` depends on
+      // nothing in flight (this also excludes every self-overlapping match, dist < len)
+      const bool near = cm & (my_pos + mlen > fenced + dist);
+      if (__ballot(near) == 0) {
+        do {
+          const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+          mm &= mm - 1;
+          const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+          const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+          const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
+          const int64_t src0 = (int64_t)dst - (int64_t)d;
+          if (len <= kWave && pend_n < kPend) {  // load now, store in the next round
+            const int64_t si = src0 + lane;
+            const uint8_t *sp = si < 0 ? O.dict + ((int64_t)O.dlen + si) : O.out + si;
+            // (one load per slot, written straight into the slot's register: a select on the
+            // loaded value would make the wave wait for it here)
+#pragma unroll
+            for (int q = 0; q < kPend; q++)
+              if (q == (int)pend_n) {
+                if (lane < len) pval[q] = *sp;
+                plen[q] = len;
+                pdst[q] = dst;
+              }
+            pend_n++;
+          } else {
+            for (uint32_t i = lane; i < len; i += kWave) {
+              const int64_t si = src0 + i;
+              const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+              O.out[dst + i] = byte;
+            }
+          }
+        } while (mm);
+      } else {
+        // in order, each one seeing everything stored before it
+        do {
+          const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+          mm &= mm - 1;
+          const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+          const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+          const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const int64_t src0 = (int64_t)dst - (int64_t)d;
+          for (uint32_t i = lane; i < len; i += kWave) {
+            const uint32_t jj = d >= len ? i : (i % d);
+            const int64_t si = src0 + jj;
+            const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+            O.out[dst + i] = byte;
+          }
+        } while (mm);
       }
     }
     if (first == 64) {  // the whole window was consumed
       O.opos += run;
       bp += k;
       continue;
+    }
+    // ---- a stop: nothing may stay deferred past this round
+    if (pend_n) {
+#pragma unroll
+      for (int q = 0; q < kPend; q++)
+        if (q < (int)pend_n && lane < plen[q]) O.out[pdst[q] + lane] = (uint8_t)pval[q];
+      pend_n = 0;
     }
     // ---- the stopping token
     const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
@@ -486,7 +549,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
           build_table(DT, lens + 288, 32, 5, kLutBits, lane);
           fixed_ready = 1;
         }
-        status = decode_block(LT, DT, R, O, lane, s_in);
+        status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
       } else if (type == 2) {  // LD:2506-2615
         fixed_ready = 0;
         const uint32_t nlen = br_read(R, 5, lane) + 257;
@@ -544,7 +607,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
         err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
-        status = decode_block(LT, DT, R, O, lane, s_in);
+        status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
       } else {
         status = -1;
       }
