@@ -374,45 +374,146 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
 }
 
 // ------------------------------------------------------------------ k_parse_lazy
-// LD:1318-1476, lazy branch.  One lane per (stream, block); parse state is reset per
-// block (Q6).  Reads the per-position best match, writes tokens.
-__global__ void k_parse_lazy(Batch B) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t s = gid / B.max_blocks, b = gid % B.max_blocks;
+// LD:1318-1476, lazy branch: the state machine that turns the per-position best matches
+// into tokens.  Parse state is reset per deflate block (Q6), so a block is the unit.
+//
+// What the machine carries from one iteration to the next is less than it looks.  With
+// L(x), Dist(x) the best match at position x (independent of the parse, Q3/Q4):
+//  * it arrives at iteration i with match_available set only from iteration i-1, and the
+//    lookup there was not gated off (a gate `prev_len >= max_lazy_evaluation` makes that
+//    iteration emit prev's match and clear match_available), so prev_len/prev_dist are
+//    L(i-1)/Dist(i-1);
+//  * the stale cur_len that survives a match (Q5) is <= prev_len < max_lazy or is the 0
+//    of a gated lookup, so the gate of the next iteration is always open.
+// Hence the token at position x is decided by L(x), Dist(x), L(x+1) alone:
+//      match(x)  iff  usable(L(x), Dist(x))  and  look(x) <= L(x),
+//      look(x) = L(x+1) if L(x) < max_lazy and x+1 is inside the block, else 0   (LD:1349)
+// and the parse is the walk x -> x + (match ? L(x) : 1) from the block's first position.
+// (tests compare this against the oracle's literal state machine.)
+//
+// One workgroup takes a block, tile by tile (8192 positions): the candidate token of every
+// position is computed with one lane per position (coalesced) into LDS; then the walk is
+// found by relaxation over 256 chunks of 32 positions: every lane walks its chunk from an
+// assumed entry position, entries are re-derived as the running maximum of the exits to
+// the left, lanes whose entry changed walk again, until nothing changes (chunk 0 is exact
+// from the start and every repeat fixes at least one more chunk; two or three repeats are
+// the rule).  Visited positions (a 32-bit mask per lane) are scanned and their tokens
+// written out.
+constexpr int kParseThreads = 256;
+constexpr uint32_t kParseChunk = 32;
+constexpr uint32_t kParseTile = kParseThreads * kParseChunk;  // 8192 positions
+constexpr int kParseRounds = kParseTile / kParseThreads;      // positions per thread when staging
+
+// LDS slot of tile-relative position j: one pad word per chunk, so that lanes walking one
+// chunk each hit different banks
+__device__ inline uint32_t parse_slot(uint32_t j) { return j + (j >> 5); }
+
+__global__ __launch_bounds__(kParseThreads) void k_parse_lazy(Batch B) {
+  __shared__ uint32_t s_tok[kParseTile + kParseTile / 32 + 2];
+  __shared__ uint32_t s_wmax[kParseThreads / kWave];
+  __shared__ uint32_t s_off[kParseThreads];
+  __shared__ uint32_t s_tot[kParseThreads / kWave];
+  __shared__ uint32_t s_tile_tot, s_tile_exit;
+  const uint32_t unit = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t s = unit / B.max_blocks, b = unit % B.max_blocks;
+  const uint32_t c = threadIdx.x, lane = c & 63, wave = c >> 6;
   if (s >= B.count) return;
   const uint32_t n = stream_len(B, s);
   if (b >= num_blocks(n)) return;
-  const uint32_t bs = block_start(b), be = block_end(b, n);
-  const uint32_t D = B.dlen;
-  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
-  const uint32_t *m = B.bufB + (size_t)s * B.nvp;
-  uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
-  const LevelCfg cfg = level_cfg(B.level);
-
-  uint32_t i = bs, ntok = 0;
-  bool avail = false;
-  uint32_t cur_len = 0, cur_dist = 0;
-  while (i <= be + 1) {
-    const uint32_t prev_len = cur_len, prev_dist = cur_dist;
-    cur_len = 0;
-    if (i <= be && prev_len < (uint32_t)cfg.max_lazy) {  // LD:1349-1350
-      const uint32_t mm = m[i - 1];
-      cur_len = mm >> 16;
-      if (cur_len) cur_dist = mm & 0xFFFF;
-    }
-    if (avail && (prev_len > 3 || (prev_len == 3 && prev_dist < 4096)) && cur_len <= prev_len) {
-      tok[ntok++] = tok_match(prev_len, prev_dist);  // match for position i-1
-      i += prev_len - 1;
-      avail = false;
-    } else if (avail) {
-      tok[ntok++] = V[D + i - 2];  // literal at position i-1
-      i++;
-    } else {
-      avail = true;
-      i++;
-    }
+  if (block_end(b, n) < block_start(b)) {  // the one block of an empty stream
+    if (c == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = 0;
+    return;
   }
-  B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
+  const uint32_t xb0 = block_start(b) - 1, xb1 = block_end(b, n) - 1;  // 0-based, inclusive
+  const uint8_t *Vd = B.vbuf + (size_t)s * (B.nvp + kVPad) + B.dlen;
+  const uint32_t *m = B.bufB + (size_t)s * B.nvp;
+  uint32_t *tok = B.bufA + (size_t)s * B.nvp + xb0;
+  const uint32_t max_lazy = (uint32_t)level_cfg(B.level).max_lazy;
+
+  uint32_t tile_entry = xb0, tok_base = 0;
+  for (uint32_t x0 = xb0; x0 <= xb1; x0 += kParseTile) {
+    // ---- candidate token of every position of the tile
+    uint32_t mm[kParseRounds], lit[kParseRounds];
+#pragma unroll
+    for (int r = 0; r < kParseRounds; r++) {
+      const uint32_t x = x0 + r * kParseThreads + c;
+      mm[r] = x <= xb1 ? m[x] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kParseRounds; r++) {
+      const uint32_t x = x0 + r * kParseThreads + c;
+      lit[r] = x <= xb1 ? (uint32_t)Vd[x] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kParseRounds; r++) s_tok[parse_slot(r * kParseThreads + c)] = mm[r];
+    if (c == 0) s_tok[parse_slot(kParseTile)] = x0 + kParseTile <= xb1 ? m[x0 + kParseTile] : 0u;
+    __syncthreads();
+    uint32_t nx[kParseRounds];
+#pragma unroll
+    for (int r = 0; r < kParseRounds; r++) nx[r] = s_tok[parse_slot(r * kParseThreads + c + 1)];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kParseRounds; r++) {
+      const uint32_t x = x0 + r * kParseThreads + c;
+      const uint32_t pl = mm[r] >> 16, pd = mm[r] & 0xFFFF;
+      const uint32_t look = (pl < max_lazy && x + 1 <= xb1) ? nx[r] >> 16 : 0u;
+      const bool usable = pl > 3 || (pl == 3 && pd < 4096);
+      s_tok[parse_slot(r * kParseThreads + c)] = (usable && look <= pl) ? tok_match(pl, pd) : lit[r];
+    }
+    __syncthreads();
+
+    // ---- the walk, by relaxation over chunks
+    const uint32_t cs = x0 + c * kParseChunk;
+    const uint32_t cend = cs + kParseChunk <= xb1 + 1 ? cs + kParseChunk : xb1 + 1;  // <= cs: empty
+    uint32_t entry = c == 0 ? tile_entry : cs, exit_x, mask;
+    bool redo = true;
+    for (;;) {
+      if (redo) {
+        uint32_t q = entry;
+        mask = 0;
+        while (q < cend) {
+          const uint32_t t = s_tok[parse_slot(q - x0)];
+          mask |= 1u << (q - cs);
+          q += (t >> 31) ? ((t >> 16) & 0x1FF) + 3 : 1u;
+        }
+        exit_x = q;
+      }
+      // entry of chunk c = the largest exit to its left (exits of the true walk never decrease)
+      uint32_t inc = exit_x;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= (uint32_t)off && t > inc) inc = t;
+      }
+      if (lane == 63) s_wmax[wave] = inc;
+      __syncthreads();
+      uint32_t e = tile_entry;
+      for (uint32_t w = 0; w < wave; w++) e = s_wmax[w] > e ? s_wmax[w] : e;
+      const uint32_t left = __shfl_up(inc, 1);
+      if (lane > 0 && left > e) e = left;
+      redo = e != entry;
+      entry = e;
+      if (!__syncthreads_or(redo)) break;
+    }
+
+    // ---- emit the visited positions' tokens
+    const uint32_t cnt = __popc(mask);
+    scan256_exclusive(cnt, c, s_off, s_tot);
+    uint32_t o = tok_base + s_off[c];
+    while (mask) {
+      const uint32_t bit = (uint32_t)__builtin_ctz(mask);
+      mask &= mask - 1;
+      tok[o++] = s_tok[parse_slot(cs + bit - x0)];
+    }
+    if (c == kParseThreads - 1) {
+      s_tile_tot = s_off[c] + cnt;
+      s_tile_exit = exit_x > entry ? exit_x : entry;
+    }
+    __syncthreads();
+    tok_base += s_tile_tot;
+    tile_entry = s_tile_exit;
+  }
+  if (c == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = tok_base;
 }
 
 // ------------------------------------------------------------------ k_lz_greedy

@@ -267,8 +267,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
         const uint32_t tiles = (uint32_t)((max_in_len + kTile - 1) / kTile);
         if (tiles && vd) LAUNCH("k_match_lazy", k_match_lazy<true>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
         if (tiles && !vd) LAUNCH("k_match_lazy", k_match_lazy<false>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
-        const uint32_t units = c * max_blocks;
-        LAUNCH("k_parse_lazy", k_parse_lazy, (units + 63) / 64, 64, 0, B);
+        LAUNCH("k_parse_lazy", k_parse_lazy, c * max_blocks, kParseThreads, 0, B);
       } else {
         HIPCHK(hipMemsetAsync(B.bufB, 0, (size_t)c * 4ull * nvp, g_stream));
         LAUNCH("k_lz_greedy", k_lz_greedy, (c + 63) / 64, 64, 0, B);
