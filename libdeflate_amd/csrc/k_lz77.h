@@ -432,54 +432,75 @@ __global__ __launch_bounds__(kParseThreads) void k_parse_lazy(Batch B) {
 
   uint32_t tile_entry = xb0, tok_base = 0;
   for (uint32_t x0 = xb0; x0 <= xb1; x0 += kParseTile) {
-    // ---- candidate token of every position of the tile
-    uint32_t mm[kParseRounds], lit[kParseRounds];
+    // ---- candidate token of every position of the tile (all loads are issued before any
+    // of them is waited for; addresses are clamped rather than branched around)
+    uint32_t tk[kParseRounds];
+    {
+      uint32_t mm[kParseRounds];
 #pragma unroll
-    for (int r = 0; r < kParseRounds; r++) {
-      const uint32_t x = x0 + r * kParseThreads + c;
-      mm[r] = x <= xb1 ? m[x] : 0u;
+      for (int r = 0; r < kParseRounds; r++) {
+        const uint32_t x = x0 + r * kParseThreads + c;
+        const uint32_t xc = x <= xb1 ? x : xb1;
+        mm[r] = m[xc];
+        tk[r] = Vd[xc];
+      }
+      const uint32_t xe = x0 + kParseTile <= xb1 ? x0 + kParseTile : xb1;
+      const uint32_t edge = m[xe];
+#pragma unroll
+      for (int r = 0; r < kParseRounds; r++) {
+        const uint32_t x = x0 + r * kParseThreads + c;
+        s_tok[parse_slot(r * kParseThreads + c)] = x <= xb1 ? mm[r] : 0u;
+      }
+      if (c == 0) s_tok[parse_slot(kParseTile)] = x0 + kParseTile <= xb1 ? edge : 0u;
     }
-#pragma unroll
-    for (int r = 0; r < kParseRounds; r++) {
-      const uint32_t x = x0 + r * kParseThreads + c;
-      lit[r] = x <= xb1 ? (uint32_t)Vd[x] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < kParseRounds; r++) s_tok[parse_slot(r * kParseThreads + c)] = mm[r];
-    if (c == 0) s_tok[parse_slot(kParseTile)] = x0 + kParseTile <= xb1 ? m[x0 + kParseTile] : 0u;
     __syncthreads();
-    uint32_t nx[kParseRounds];
-#pragma unroll
-    for (int r = 0; r < kParseRounds; r++) nx[r] = s_tok[parse_slot(r * kParseThreads + c + 1)];
-    __syncthreads();
 #pragma unroll
     for (int r = 0; r < kParseRounds; r++) {
-      const uint32_t x = x0 + r * kParseThreads + c;
-      const uint32_t pl = mm[r] >> 16, pd = mm[r] & 0xFFFF;
-      const uint32_t look = (pl < max_lazy && x + 1 <= xb1) ? nx[r] >> 16 : 0u;
-      const bool usable = pl > 3 || (pl == 3 && pd < 4096);
-      s_tok[parse_slot(r * kParseThreads + c)] = (usable && look <= pl) ? tok_match(pl, pd) : lit[r];
+      const uint32_t j = r * kParseThreads + c, x = x0 + j;
+      const uint32_t me = s_tok[parse_slot(j)], nx = s_tok[parse_slot(j + 1)];
+      const uint32_t pl = me >> 16, pd = me & 0xFFFF;
+      const uint32_t look = ((pl < max_lazy) & (x + 1 <= xb1)) ? nx >> 16 : 0u;
+      const bool usable = (pl > 3) | ((pl == 3) & (pd < 4096));
+      const uint32_t sel = 0u - (uint32_t)(usable & (look <= pl));  // all ones: match
+      tk[r] = (((1u << 31) | ((pl - 3) << 16) | (pd - 1)) & sel) | (tk[r] & ~sel);
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kParseRounds; r++) s_tok[parse_slot(r * kParseThreads + c)] = tk[r];
     __syncthreads();
 
-    // ---- the walk, by relaxation over chunks
+    // ---- the walk, by relaxation over chunks.  A lane keeps the 32 step widths of its chunk
+    // in registers, so a (re-)walk is straight-line code with no memory access.
     const uint32_t cs = x0 + c * kParseChunk;
-    const uint32_t cend = cs + kParseChunk <= xb1 + 1 ? cs + kParseChunk : xb1 + 1;  // <= cs: empty
-    uint32_t entry = c == 0 ? tile_entry : cs, exit_x, mask;
+    const uint32_t clen = cs > xb1 ? 0u : (xb1 + 1 - cs < kParseChunk ? xb1 + 1 - cs : kParseChunk);
+    uint32_t st[kParseChunk];
+#pragma unroll
+    for (int k = 0; k < (int)kParseChunk; k++) {
+      const uint32_t t = s_tok[c * (kParseChunk + 1) + k];
+      st[k] = (t >> 31) ? ((t >> 16) & 0x1FF) + 3 : 1u;
+    }
+    uint32_t entry = c == 0 ? tile_entry : cs, exit_x = 0, mask = 0;
     bool redo = true;
     for (;;) {
       if (redo) {
-        uint32_t q = entry;
-        mask = 0;
-        while (q < cend) {
-          const uint32_t t = s_tok[parse_slot(q - x0)];
-          mask |= 1u << (q - cs);
-          q += (t >> 31) ? ((t >> 16) & 0x1FF) + 3 : 1u;
+        // (entry >= cs always: it is an exit of a chunk to the left, or the assumed cs)
+        const uint32_t e0 = entry - cs;
+        mask = e0 < clen ? 1u << e0 : 0u;
+        exit_x = entry;
+#pragma unroll
+        for (int k = 0; k < (int)kParseChunk; k++) {
+          const bool on = (mask >> k) & 1;
+          const uint32_t nx = k + st[k];
+          const bool inside = nx < clen;
+          mask |= (on & inside) ? 1u << (nx & 31) : 0u;
+          exit_x = (on & !inside) ? cs + nx : exit_x;
         }
-        exit_x = q;
       }
-      // entry of chunk c = the largest exit to its left (exits of the true walk never decrease)
-      uint32_t inc = exit_x;
+      // entry of chunk c = the largest exit to its left (exits of the true walk never
+      // decrease).  A chunk the walk only passes through (or an empty one) contributes
+      // nothing of its own, so that a wrong value to its left is gone the moment its source
+      // is corrected instead of being handed on one chunk per repeat.
+      uint32_t inc = mask ? exit_x : 0u;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t t = __shfl_up(inc, off);
