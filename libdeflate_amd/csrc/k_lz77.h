@@ -175,19 +175,52 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   }
 
   // links: neighbours in sorted order that share the trigram
-  for (uint32_t r = tid; r < nv; r += kSortThreads) {
-    uint32_t v = bufA[r];
-    uint32_t dlt = 0;
-    if (r > 0) {
-      uint32_t u = bufA[r - 1];
-      const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
-      const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
-      if (tu == tv) {
-        uint32_t d = v - u;
-        if (d <= kWindow) dlt = d;
+  if (V_LDS) {
+    // Scattering 2-byte links by position straight to memory cost as much as the whole sort.
+    // Instead: (a) link values in sorted order, coalesced, into the free ping-pong buffer;
+    // (b) V is no longer needed, so its LDS holds the links of 65536 positions at a time:
+    // scatter there, then copy out in order.
+    uint16_t *dl = (uint16_t *)bufB;
+    for (uint32_t r = tid; r < nv; r += kSortThreads) {
+      uint32_t dlt = 0;
+      if (r > 0) {
+        const uint32_t v = bufA[r], u = bufA[r - 1];
+        const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
+        const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
+        if (tu == tv && v - u <= kWindow) dlt = v - u;
       }
+      dl[r] = (uint16_t)dlt;
     }
-    prevd[v] = (uint16_t)dlt;
+    __syncthreads();
+    uint16_t *l16 = (uint16_t *)ldsV;
+    const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~63u;  // positions whose links fit V's LDS
+    for (uint32_t h0 = 0; h0 < nv; h0 += H) {
+      for (uint32_t r = tid; r < nv; r += kSortThreads) {
+        const uint32_t v = bufA[r];
+        if (v - h0 < H) l16[v - h0] = dl[r];
+      }
+      __syncthreads();
+      const uint32_t cnt = nv - h0 < H ? nv - h0 : H;  // prevd rows are 4-byte aligned (nvp % 16 == 0)
+      const uint32_t *src32 = (const uint32_t *)l16;
+      uint32_t *dst32 = (uint32_t *)(prevd + h0);
+      for (uint32_t i = tid; i < (cnt + 1) / 2; i += kSortThreads) dst32[i] = src32[i];
+      __syncthreads();
+    }
+  } else {
+    for (uint32_t r = tid; r < nv; r += kSortThreads) {
+      uint32_t v = bufA[r];
+      uint32_t dlt = 0;
+      if (r > 0) {
+        uint32_t u = bufA[r - 1];
+        const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
+        const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
+        if (tu == tv) {
+          uint32_t d = v - u;
+          if (d <= kWindow) dlt = d;
+        }
+      }
+      prevd[v] = (uint16_t)dlt;
+    }
   }
 #undef VBYTE
 }
