@@ -297,6 +297,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   // full compare -- run once per round for all lanes that need them instead of per step.
   constexpr uint32_t steps_per_round = 8;
   bool active = false, cmpp = false, pending = false, exhausted = false, seen_seed = false;
+  bool open = true;  // best < nice_length and best < maxlen: the walk may go on (LD:1389)
   uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, t2 = 0, dsave = 0;
   uint32_t depth = 0;
   uint64_t tw = 0;
@@ -308,8 +309,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   {                                                                                              \
     depth -= (cond) ? 1u : 0u;                                                                   \
     const uint32_t cn_ = cb - (dn_);                                                             \
-    bool go_ = (cond) & (best < nice) & (depth != 0) & (best < maxlen) & ((dn_) != 0) &          \
-               (vb - cn_ <= kWindow);                                                            \
+    bool go_ = (cond) & open & (depth != 0) & ((dn_) != 0) & (vb - cn_ <= kWindow);             \
     if (HAS_DICT) { /* dictionary side of V (Q10) */                                             \
       const uint32_t c_ = cn_ + wbase;                                                           \
       const bool in_dict_ = c_ < D, deep_ = c_ + 2 < D;                                          \
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
           best = L;
           bdist = vb - cb;
           t2 = (uint32_t)lb8[vb + best - 1] | ((uint32_t)lb8[vb + best] << 8);
+          open = (best < nice) & (best < maxlen);
         }
         LDH_ADVANCE(true, dsave);
         cmpp = false;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
             depth = (uint32_t)cfg.max_chain;  // Q3
             best = 0;
             bdist = 0;
+            open = true;
             active = (d0 != 0) & (d0 <= kWindow);  // chain empty / LD:1365
             seen_seed = HAS_DICT && active && (cb + wbase < D) && !(cb + wbase + 2 < D);
             pending = true;
