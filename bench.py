@@ -196,6 +196,17 @@ def main():
         alg = S * L + comp_bytes
         avg_s = ms / 1e3 / max(launches, 1)
         achieved = alg / avg_s / 1e9
+        # HBM-side bytes per launch of that kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this
+        # same command, committed under profiles/ (a process cannot collect its own counters); null for any
+        # other workload than the one they were taken on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("workload") == "%dx%d level %d" % (S, L, args.level):
+                traffic = pt["kernels"][name]["total"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "input GB/s compress+decompress, level %d, batched 128 KB strings" % args.level,
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +220,7 @@ def main():
                        "compress_GBps": S * L * args.steps / 1e6 / max(sum(v[0] for k, v in prof.items() if k in compress_kernels), 1e-9),
                        "decompress_GBps": S * L * args.steps / 1e6 / max(sum(v[0] for k, v in prof.items() if k not in compress_kernels), 1e-9)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3},
         }
         if not args.no_cpu_baseline:
