@@ -78,6 +78,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   uint32_t *bufA = B.bufA + (size_t)s * B.nvp;
   uint32_t *bufB = B.bufB + (size_t)s * B.nvp;
   uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+  // where the sorted array ends up; greedy levels also get its inverse (rank of a position)
+  uint32_t *srt = B.want_rank ? B.bufC + (size_t)s * B.nvp : bufA;
+  uint32_t *rank = bufB;
 #define VBYTE(i) (V_LDS ? (uint32_t)ldsV[(i)] : (uint32_t)V[(i)])
 
   if (tid < 256) s_hist[tid] = 0;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   for (int pass = 0; pass < 3; pass++) {
     const uint32_t shift = 2 - pass;  // digit of v is V[v + shift]
     const uint32_t *src = pass == 1 ? bufA : bufB;
-    uint32_t *dst = pass == 1 ? bufB : bufA;
+    uint32_t *dst = pass == 1 ? bufB : (pass == 2 ? srt : bufA);
     {  // bin bases: histogram of V[shift .. shift+nv-1] (zero padded), exclusive scan
       uint32_t cnt = 0;
       if (tid < 256) {
@@ -180,23 +183,24 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     // Instead: (a) link values in sorted order, coalesced, into the free ping-pong buffer;
     // (b) V is no longer needed, so its LDS holds the links of 65536 positions at a time:
     // scatter there, then copy out in order.
-    uint16_t *dl = (uint16_t *)bufB;
+    uint16_t *dl = (uint16_t *)(B.want_rank ? bufA : bufB);
     for (uint32_t r = tid; r < nv; r += kSortThreads) {
       uint32_t dlt = 0;
       if (r > 0) {
-        const uint32_t v = bufA[r], u = bufA[r - 1];
+        const uint32_t v = srt[r], u = srt[r - 1];
         const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
         const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
         if (tu == tv && v - u <= kWindow) dlt = v - u;
       }
       dl[r] = (uint16_t)dlt;
+      if (B.want_rank && r < nv) rank[srt[r]] = r;
     }
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
     const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~63u;  // positions whose links fit V's LDS
     for (uint32_t h0 = 0; h0 < nv; h0 += H) {
       for (uint32_t r = tid; r < nv; r += kSortThreads) {
-        const uint32_t v = bufA[r];
+        const uint32_t v = srt[r];
         if (v - h0 < H) l16[v - h0] = dl[r];
       }
       __syncthreads();
@@ -208,10 +212,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     }
   } else {
     for (uint32_t r = tid; r < nv; r += kSortThreads) {
-      uint32_t v = bufA[r];
+      uint32_t v = srt[r];
       uint32_t dlt = 0;
       if (r > 0) {
-        uint32_t u = bufA[r - 1];
+        uint32_t u = srt[r - 1];
         const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
         const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
         if (tu == tv) {
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
         }
       }
       prevd[v] = (uint16_t)dlt;
+      if (B.want_rank) rank[v] = r;
     }
   }
 #undef VBYTE
@@ -574,70 +579,137 @@ __global__ __launch_bounds__(kParseThreads) void k_parse_lazy(Batch B) {
 
 // ------------------------------------------------------------------ k_lz_greedy
 // Levels 1-3 (LD:1318-1476, non-lazy branch).  Positions inside a match longer than
-// max_insert_length are not inserted (Q4), so the candidate set depends on the parse:
-// one lane walks one stream.  flags[q] = 1 once stream position q is in a chain
-// (bufB must be zeroed by the caller).
-__global__ void k_lz_greedy(Batch B) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// max_insert_length never enter the hash chains (Q4, LD:1249/1454), so the candidate set of
+// a position depends on the parse before it: the walk over a stream is serial.  One
+// wavefront takes one stream and spends its lanes on the candidates of the current position:
+// in the array sorted by (trigram, position) the chain of position v is the entries before
+// rank[v], so 64 candidates are fetched with one coalesced load, filtered with ballots
+// (same trigram, window LD:1365, dictionary rule Q10/LD:1394, "was inserted" from a bitmap of
+// the last 65536 positions in LDS), the nearest max_chain survivors are compared in
+// parallel, and nice_length (LD:1389) cuts the list where the serial walk would have stopped.
+__device__ inline uint32_t gld4(const uint8_t *V, uint32_t off) {  // V is 16-byte aligned and padded
+  const uint32_t *w = (const uint32_t *)(V + (off & ~3u));
+  return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3);
+}
+
+__global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
+  __shared__ uint32_t s_ins[2048];  // bit (q & 65535): stream position q is in a hash chain (LD:1347)
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= B.count) return;
   const uint32_t n = stream_len(B, s), D = B.dlen;
   const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
-  const uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
-  uint8_t *flags = (uint8_t *)(B.bufB + (size_t)s * B.nvp);
+  const uint32_t *sorted = B.bufC + (size_t)s * B.nvp;
+  const uint32_t *rank = B.bufB + (size_t)s * B.nvp;
   const LevelCfg cfg = level_cfg(B.level);
+  const uint32_t nice = (uint32_t)cfg.nice, max_chain = (uint32_t)cfg.max_chain;
+  const uint32_t max_insert = (uint32_t)cfg.max_lazy;  // max_insert_length for these levels
   const uint32_t nblk = num_blocks(n);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (uint32_t i = lane; i < 2048; i += kWave) s_ins[i] = 0;
+  __syncthreads();
 
   for (uint32_t b = 0; b < nblk; b++) {
-    const uint32_t bs = block_start(b), be = block_end(b, n);
+    const uint32_t bs = block_start(b), be = block_end(b, n);  // 1-based, inclusive
     uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
-    uint32_t ntok = 0, i = bs;
-    while (i <= be) {
-      const uint32_t v = i - 1 + D;
-      flags[i - 1] = 1;  // LD:1347
-      uint32_t cur_len = 0, cur_dist = 0;
-      if (i + 2 <= be) {
-        uint32_t maxlen = be - i + 1;
+    uint32_t ntok = 0, x = bs - 1;  // x: 0-based stream position
+    while (x + 1 <= be) {
+      const uint32_t v = x + D;
+      const uint32_t my = __builtin_amdgcn_readfirstlane(gld4(V, v));
+      uint32_t best = 0, bdist = 0;
+      if (x + 3 <= be) {  // LD:1349
+        uint32_t maxlen = be - x;
         if (maxlen > kMaxMatch) maxlen = kMaxMatch;
-        uint32_t c = v;
-        int depth = cfg.max_chain;
+        const uint32_t key = my & 0xFFFFFFu;
+        const uint32_t r = __builtin_amdgcn_readfirstlane(rank[v]);
+        uint32_t taken = 0;
         bool seen_seed = false;
-        while (depth > 0) {
-          const uint32_t d = prevd[c];
-          if (d == 0) break;
-          c -= d;
-          if (v - c > kWindow) break;
-          if (c >= D) {
-            if (!flags[c - D]) continue;  // never inserted: not in the reference's chain
-          } else if (c + 2 < D) {
-            if (seen_seed) break;
-          } else {
-            seen_seed = true;
+        for (uint32_t base = 0;; base += kWave) {
+          const bool have = r >= 1 + base + lane;
+          const uint32_t c = have ? sorted[r - 1 - base - lane] : 0u;
+          const uint32_t cw = have ? gld4(V, c) : ~my;
+          const bool ok = have && (cw & 0xFFFFFFu) == key && v - c <= kWindow;  // (another group's c may exceed v)
+          // the chain is the run of ok lanes from lane 0
+          const unsigned long long notok = ~__ballot(ok);
+          const uint32_t first_bad = notok ? (uint32_t)__builtin_ctzll(notok) : 64u;
+          const bool in_chain = lane < first_bad;
+          const bool in_dict = c < D, deep = in_dict && c + 2 < D;
+          const unsigned long long seedm = __ballot(in_chain && in_dict && !deep);
+          const bool seen_before = seen_seed || (seedm & below) != 0;
+          const unsigned long long brk = __ballot(in_chain && deep && seen_before);  // LD:1394
+          const uint32_t first_brk = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
+          const uint32_t q = c - D;
+          const bool inserted = in_dict || ((s_ins[(q >> 5) & 2047] >> (q & 31)) & 1);
+          const bool cand = in_chain && lane < first_brk && inserted;
+          const unsigned long long candm = __ballot(cand);
+          const bool sel = cand && taken + (uint32_t)__popcll(candm & below) < max_chain;  // LD:1362
+          uint32_t L = 0;
+          if (sel) {
+            L = 3;
+            if ((cw >> 24) == (my >> 24)) {
+              L = 4;
+              while (L < maxlen) {
+                const uint32_t y = gld4(V, c + L) ^ gld4(V, v + L);
+                if (y) {
+                  L += __builtin_ctz(y) >> 3;
+                  break;
+                }
+                L += 4;
+              }
+            }
+            if (L > maxlen) L = maxlen;
           }
-          uint32_t L = 3;
-          while (L < maxlen && V[c + L] == V[v + L]) L++;
-          if (L > cur_len) {
-            cur_len = L;
-            cur_dist = v - c;
+          const unsigned long long selm = __ballot(sel);
+          // nice_length: the walk stops at the nearest candidate that reaches it (LD:1389)
+          const unsigned long long nicem = __ballot(sel && L >= nice);
+          const uint32_t first_nice = nicem ? (uint32_t)__builtin_ctzll(nicem) : 64u;
+          // longest of the candidates up to there, nearest among equals (LD:1385)
+          unsigned long long m = selm & (first_nice >= 63 ? ~0ull : ((2ull << first_nice) - 1ull));
+          if (m) {
+#pragma unroll
+            for (int bit = 8; bit >= 0; bit--) {
+              const unsigned long long t = m & __ballot((L >> bit) & 1);
+              if (t) m = t;
+            }
+            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+            const uint32_t Lmax = __builtin_amdgcn_readlane(L, j);
+            if (Lmax > best) {
+              best = Lmax;
+              bdist = v - __builtin_amdgcn_readlane(c, j);
+            }
           }
-          if (cur_len >= (uint32_t)cfg.nice) break;
-          depth--;
+          taken += (uint32_t)__popcll(selm);
+          seen_seed = seen_seed || seedm != 0;
+          if (nicem || first_bad < 64 || first_brk < 64 || taken >= max_chain) break;
         }
       }
-      if (cur_len > 3 || (cur_len == 3 && cur_dist < 4096)) {
-        tok[ntok++] = tok_match(cur_len, cur_dist);
-        if (cur_len <= (uint32_t)cfg.max_lazy)  // max_insert_length, LD:1249,1454
-          for (uint32_t j = i + 1; j <= i + cur_len - 1; j++) flags[j - 1] = 1;
-        i += cur_len;
+      // ---- the token, and which of its positions enter the chains
+      uint32_t len = 1;
+      bool interior_on = true;
+      if (best > 3 || (best == 3 && bdist < 4096)) {
+        if (lane == 0) tok[ntok] = tok_match(best, bdist);
+        len = best;
+        interior_on = best <= max_insert;  // LD:1454
       } else {
-        tok[ntok++] = V[v];
-        i++;
+        if (lane == 0) tok[ntok] = my & 0xFFu;
       }
+      ntok++;
+      {
+        const uint32_t first = x, last = x + len - 1, wi = (first >> 5) + lane;
+        if (wi <= (last >> 5)) {
+          const uint32_t lo = first > wi * 32 ? first - wi * 32 : 0u;
+          const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
+          const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+          const uint32_t val = interior_on ? mask : (lane == 0 ? 1u << (first & 31) : 0u);
+          s_ins[wi & 2047] = (s_ins[wi & 2047] & ~mask) | val;
+        }
+      }
+      __syncthreads();
+      x += len;
     }
-    B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
+    if (lane == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
   }
 }
 
-// strategy "huffman_only" (LD:1833-1845): every byte is a literal token.
 __global__ void k_tokens_literal(Batch B) {
   const uint32_t s = blockIdx.x;
   const uint32_t n = stream_len(B, s), D = B.dlen;

@@ -39,7 +39,7 @@ struct DevBuf {
   size_t cap = 0;
 };
 // workspace (grow-only)
-DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_blocks, g_adler, g_misc32a, g_misc32b;
+DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_bufC, g_blocks, g_adler, g_misc32a, g_misc32b;
 // staging for the host-pointer entry points
 DevBuf g_h_in, g_h_off, g_h_out, g_h_len, g_h_aux8, g_h_aux32a, g_h_aux32b;
 
@@ -190,7 +190,8 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   const uint32_t nvp = (uint32_t)round_up((size_t)vd + max_in_len + 16, 16);
   const uint32_t max_blocks = num_blocks((uint32_t)max_in_len);
 
-  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + 8ull * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
+  const bool greedy = need_lz && !level_cfg(level).lazy;  // levels 1-3
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 12ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
 
@@ -198,6 +199,8 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   if (int rc = ensure(g_prevd, chunk * 2ull * nvp + 64)) return rc;
   if (int rc = ensure(g_bufA, chunk * 4ull * nvp + 64)) return rc;
   if (int rc = ensure(g_bufB, chunk * 4ull * nvp + 64)) return rc;
+  if (greedy)
+    if (int rc = ensure(g_bufC, chunk * 4ull * nvp + 64)) return rc;
   if (int rc = ensure(g_blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
   if (int rc = ensure(g_adler, chunk * 4 + 64)) return rc;
 
@@ -236,6 +239,8 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.prevd = (uint16_t *)g_prevd.p;
     B.bufA = (uint32_t *)g_bufA.p;
     B.bufB = (uint32_t *)g_bufB.p;
+    B.bufC = greedy ? (uint32_t *)g_bufC.p : nullptr;
+    B.want_rank = greedy ? 1u : 0u;
     B.blocks = (BlockInfo *)g_blocks.p;
     B.adler = (uint32_t *)g_adler.p;
     B.out = d_out + s0 * out_stride;
@@ -251,6 +256,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
       HIPCHK(hipMemsetAsync(g_prevd.p, 0xA5, g_prevd.cap, g_stream));
       HIPCHK(hipMemsetAsync(g_bufA.p, 0xA5, g_bufA.cap, g_stream));
       HIPCHK(hipMemsetAsync(g_bufB.p, 0xA5, g_bufB.cap, g_stream));
+      if (greedy) HIPCHK(hipMemsetAsync(g_bufC.p, 0xA5, g_bufC.cap, g_stream));
       HIPCHK(hipMemsetAsync(g_blocks.p, 0xA5, g_blocks.cap, g_stream));
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
     }
@@ -269,8 +275,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
         if (tiles && !vd) LAUNCH("k_match_lazy", k_match_lazy<false>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
         LAUNCH("k_parse_lazy", k_parse_lazy, c * max_blocks, kParseThreads, 0, B);
       } else {
-        HIPCHK(hipMemsetAsync(B.bufB, 0, (size_t)c * 4ull * nvp, g_stream));
-        LAUNCH("k_lz_greedy", k_lz_greedy, (c + 63) / 64, 64, 0, B);
+        LAUNCH("k_lz_greedy", k_lz_greedy, c, kWave, 0, B);
       }
       LAUNCH("k_histogram", k_histogram, c * max_blocks, 256, 0, B);
       LAUNCH("k_huffman", k_huffman, c * max_blocks, kWave, 0, B);
@@ -365,7 +370,7 @@ void ldh_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_device < 0) return;
   hipStreamSynchronize(g_stream);
-  for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
+  for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_bufC, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
                     &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b}) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;
