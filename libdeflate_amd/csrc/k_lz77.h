@@ -79,8 +79,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   uint32_t *bufB = B.bufB + (size_t)s * B.nvp;
   uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
   // where the sorted array ends up; greedy levels also get its inverse (rank of a position)
-  uint32_t *srt = B.want_rank ? B.bufC + (size_t)s * B.nvp : bufA;
+  // (greedy levels: entries of the final array carry the first four bytes of their position too)
+  uint2 *srt2 = B.want_rank ? (uint2 *)B.bufC + (size_t)s * B.nvp : nullptr;
   uint32_t *rank = bufB;
+#define SRT(r) (B.want_rank ? srt2[(r)].x : bufA[(r)])
 #define VBYTE(i) (V_LDS ? (uint32_t)ldsV[(i)] : (uint32_t)V[(i)])
 
   if (tid < 256) s_hist[tid] = 0;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   for (int pass = 0; pass < 3; pass++) {
     const uint32_t shift = 2 - pass;  // digit of v is V[v + shift]
     const uint32_t *src = pass == 1 ? bufA : bufB;
-    uint32_t *dst = pass == 1 ? bufB : (pass == 2 ? srt : bufA);
+    uint32_t *dst = pass == 1 ? bufB : bufA;
     {  // bin bases: histogram of V[shift .. shift+nv-1] (zero padded), exclusive scan
       uint32_t cnt = 0;
       if (tid < 256) {
@@ -170,7 +172,15 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < kSortItems; j++)
-        if (e[j] != 0xFFFFFFFFu) dst[s_bprev[d[j]] + s_pre[wave][d[j]] + lrank[j]] = e[j];
+        if (e[j] != 0xFFFFFFFFu) {
+          const uint32_t at = s_bprev[d[j]] + s_pre[wave][d[j]] + lrank[j];
+          if (pass == 2 && B.want_rank) {
+            const uint32_t w4 = VBYTE(e[j]) | (VBYTE(e[j] + 1) << 8) | (VBYTE(e[j] + 2) << 16) | (VBYTE(e[j] + 3) << 24);
+            srt2[at] = make_uint2(e[j], w4);
+          } else {
+            dst[at] = e[j];
+          }
+        }
       // next tile: its s_cnt updates alias neither s_pre nor s_bprev; the barrier after them
       // orders the reads above before the next rewrite.
     }
@@ -187,20 +197,20 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     for (uint32_t r = tid; r < nv; r += kSortThreads) {
       uint32_t dlt = 0;
       if (r > 0) {
-        const uint32_t v = srt[r], u = srt[r - 1];
+        const uint32_t v = SRT(r), u = SRT(r - 1);
         const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
         const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
         if (tu == tv && v - u <= kWindow) dlt = v - u;
       }
       dl[r] = (uint16_t)dlt;
-      if (B.want_rank && r < nv) rank[srt[r]] = r;
+      if (B.want_rank) rank[SRT(r)] = r;
     }
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
     const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~63u;  // positions whose links fit V's LDS
     for (uint32_t h0 = 0; h0 < nv; h0 += H) {
       for (uint32_t r = tid; r < nv; r += kSortThreads) {
-        const uint32_t v = srt[r];
+        const uint32_t v = SRT(r);
         if (v - h0 < H) l16[v - h0] = dl[r];
       }
       __syncthreads();
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     }
   } else {
     for (uint32_t r = tid; r < nv; r += kSortThreads) {
-      uint32_t v = srt[r];
+      uint32_t v = SRT(r);
       uint32_t dlt = 0;
       if (r > 0) {
-        uint32_t u = srt[r - 1];
+        uint32_t u = SRT(r - 1);
         const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
         const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
         if (tu == tv) {
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     }
   }
 #undef VBYTE
+#undef SRT
 }
 
 // ------------------------------------------------------------------ k_match_lazy
@@ -583,7 +594,8 @@ __global__ __launch_bounds__(kParseThreads) void k_parse_lazy(Batch B) {
 // a position depends on the parse before it: the walk over a stream is serial.  One
 // wavefront takes one stream and spends its lanes on the candidates of the current position:
 // in the array sorted by (trigram, position) the chain of position v is the entries before
-// rank[v], so 64 candidates are fetched with one coalesced load, filtered with ballots
+// rank[v] (each with the first four bytes of its position), so 64 candidates are fetched with
+// one coalesced load, filtered with ballots
 // (same trigram, window LD:1365, dictionary rule Q10/LD:1394, "was inserted" from a bitmap of
 // the last 65536 positions in LDS), the nearest max_chain survivors are compared in
 // parallel, and nice_length (LD:1389) cuts the list where the serial walk would have stopped.
@@ -598,7 +610,7 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
   if (s >= B.count) return;
   const uint32_t n = stream_len(B, s), D = B.dlen;
   const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
-  const uint32_t *sorted = B.bufC + (size_t)s * B.nvp;
+  const uint2 *sorted = (const uint2 *)B.bufC + (size_t)s * B.nvp;  // {position, its first four bytes}
   const uint32_t *rank = B.bufB + (size_t)s * B.nvp;
   const LevelCfg cfg = level_cfg(B.level);
   const uint32_t nice = (uint32_t)cfg.nice, max_chain = (uint32_t)cfg.max_chain;
@@ -612,31 +624,43 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
     const uint32_t bs = block_start(b), be = block_end(b, n);  // 1-based, inclusive
     uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
     uint32_t ntok = 0, x = bs - 1;  // x: 0-based stream position
+    // rank and first four bytes of the current position; those of the 64 positions after it
+    // are fetched while it is being worked on, so that the next position (x + token length)
+    // usually starts without a memory round trip
+    uint32_t cur_r = __builtin_amdgcn_readfirstlane(rank[x + D]);
+    uint32_t cur_w = __builtin_amdgcn_readfirstlane(gld4(V, x + D));
     while (x + 1 <= be) {
       const uint32_t v = x + D;
-      const uint32_t my = __builtin_amdgcn_readfirstlane(gld4(V, v));
+      const uint32_t my = cur_w;
+      const uint32_t pv = v + 1 + lane < D + n ? v + 1 + lane : D + n - 1;
+      const uint32_t pre_r = rank[pv], pre_w = gld4(V, pv);
       uint32_t best = 0, bdist = 0;
       if (x + 3 <= be) {  // LD:1349
         uint32_t maxlen = be - x;
         if (maxlen > kMaxMatch) maxlen = kMaxMatch;
         const uint32_t key = my & 0xFFFFFFu;
-        const uint32_t r = __builtin_amdgcn_readfirstlane(rank[v]);
+        const uint32_t r = cur_r;
         uint32_t taken = 0;
         bool seen_seed = false;
         for (uint32_t base = 0;; base += kWave) {
           const bool have = r >= 1 + base + lane;
-          const uint32_t c = have ? sorted[r - 1 - base - lane] : 0u;
-          const uint32_t cw = have ? gld4(V, c) : ~my;
+          uint2 ce = make_uint2(0u, ~my);
+          if (have) ce = sorted[r - 1 - base - lane];
+          const uint32_t c = ce.x, cw = ce.y;
           const bool ok = have && (cw & 0xFFFFFFu) == key && v - c <= kWindow;  // (another group's c may exceed v)
           // the chain is the run of ok lanes from lane 0
           const unsigned long long notok = ~__ballot(ok);
           const uint32_t first_bad = notok ? (uint32_t)__builtin_ctzll(notok) : 64u;
           const bool in_chain = lane < first_bad;
           const bool in_dict = c < D, deep = in_dict && c + 2 < D;
-          const unsigned long long seedm = __ballot(in_chain && in_dict && !deep);
-          const bool seen_before = seen_seed || (seedm & below) != 0;
-          const unsigned long long brk = __ballot(in_chain && deep && seen_before);  // LD:1394
-          const uint32_t first_brk = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
+          unsigned long long seedm = 0;
+          uint32_t first_brk = 64;
+          if (D) {  // (uniform) the dictionary rule only exists with a dictionary
+            seedm = __ballot(in_chain && in_dict && !deep);
+            const bool seen_before = seen_seed || (seedm & below) != 0;
+            const unsigned long long brk = __ballot(in_chain && deep && seen_before);  // LD:1394
+            first_brk = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
+          }
           const uint32_t q = c - D;
           const bool inserted = in_dict || ((s_ins[(q >> 5) & 2047] >> (q & 31)) & 1);
           const bool cand = in_chain && lane < first_brk && inserted;
@@ -665,17 +689,22 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
           // longest of the candidates up to there, nearest among equals (LD:1385)
           unsigned long long m = selm & (first_nice >= 63 ? ~0ull : ((2ull << first_nice) - 1ull));
           if (m) {
+            if (__popcll(m) > 6) {  // narrow the set down bit by bit of L, most significant first
 #pragma unroll
-            for (int bit = 8; bit >= 0; bit--) {
-              const unsigned long long t = m & __ballot((L >> bit) & 1);
-              if (t) m = t;
+              for (int bit = 8; bit >= 0; bit--) {
+                const unsigned long long t = m & __ballot((L >> bit) & 1);
+                if (t) m = t;
+              }
             }
-            const uint32_t j = (uint32_t)__builtin_ctzll(m);
-            const uint32_t Lmax = __builtin_amdgcn_readlane(L, j);
-            if (Lmax > best) {
-              best = Lmax;
-              bdist = v - __builtin_amdgcn_readlane(c, j);
-            }
+            do {  // (a handful of lanes: scalar scan, nearest first)
+              const uint32_t j = (uint32_t)__builtin_ctzll(m);
+              m &= m - 1;
+              const uint32_t Lj = __builtin_amdgcn_readlane(L, j);
+              if (Lj > best) {
+                best = Lj;
+                bdist = v - __builtin_amdgcn_readlane(c, j);
+              }
+            } while (m);
           }
           taken += (uint32_t)__popcll(selm);
           seen_seed = seen_seed || seedm != 0;
@@ -705,6 +734,13 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
       }
       __syncthreads();
       x += len;
+      if (len <= kWave) {
+        cur_r = __builtin_amdgcn_readlane(pre_r, len - 1);
+        cur_w = __builtin_amdgcn_readlane(pre_w, len - 1);
+      } else if (x < n) {
+        cur_r = __builtin_amdgcn_readfirstlane(rank[x + D]);
+        cur_w = __builtin_amdgcn_readfirstlane(gld4(V, x + D));
+      }
     }
     if (lane == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
   }

@@ -191,7 +191,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   const uint32_t max_blocks = num_blocks((uint32_t)max_in_len);
 
   const bool greedy = need_lz && !level_cfg(level).lazy;  // levels 1-3
-  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 12ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 16ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
 
@@ -200,7 +200,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   if (int rc = ensure(g_bufA, chunk * 4ull * nvp + 64)) return rc;
   if (int rc = ensure(g_bufB, chunk * 4ull * nvp + 64)) return rc;
   if (greedy)
-    if (int rc = ensure(g_bufC, chunk * 4ull * nvp + 64)) return rc;
+    if (int rc = ensure(g_bufC, chunk * 8ull * nvp + 64)) return rc;
   if (int rc = ensure(g_blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
   if (int rc = ensure(g_adler, chunk * 4 + 64)) return rc;
 

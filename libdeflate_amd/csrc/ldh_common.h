@@ -134,7 +134,7 @@ struct Batch {
   uint16_t *prevd;      // count * nvp   distance to the previous same-trigram position (0 none)
   uint32_t *bufA;       // count * nvp   sort scratch, then tokens
   uint32_t *bufB;       // count * nvp   sort scratch, then per-position best match (lazy) / rank of a position in the sorted array (greedy)
-  uint32_t *bufC;       // count * nvp   greedy levels only: the sorted array (bufA then holds the tokens)
+  uint32_t *bufC;       // count * 2*nvp greedy levels only: the sorted array as {position, its first 4 bytes} pairs
   uint32_t want_rank;   // k_sort_links leaves sorted array in bufC and its inverse in bufB (greedy levels)
   BlockInfo *blocks;    // count * max_blocks
   uint32_t *adler;      // count
