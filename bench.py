@@ -110,14 +110,9 @@ def main():
 
     import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from libdeflate_amd import shard
+    rank, local_rank, world = shard.env_world()
+    dist = shard.init("nccl", torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -142,30 +137,17 @@ def main():
         B.device_compress(bt, comp, stride, comp_len, pad, fmt=0, level=args.level)
         B.device_decompress_slots(comp, stride, comp_len, S, back, L, back_len, left, status, fmt=0)
 
-    def fence():
+    def dev_sync():
         B.sync()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    # untimed warm-up, then the profiled + timed steps (barrier + sync on both sides, MAX over ranks)
+    shard.timed_steps(step, 0, args.warmup, dev_sync, dist, torch, dev)
     B.profile(True)
     B.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    B.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = shard.timed_steps(step, args.steps, 0, dev_sync, dist, torch, dev)
     prof = B.profile_report()
     B.profile(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     # correctness inside the same run: exact round trip of every stream, oracle bytes on a sample
     ok = bool(torch.equal(back, data)) and int(status.abs().sum()) == 0 and int(left.sum()) == 0
@@ -180,10 +162,7 @@ def main():
         for i in range(nsamp):
             want, _ = T.o_compress(host_rows[i].tobytes(), level=args.level)
             ok = ok and cbuf[i * stride: i * stride + int(lens[i])].tobytes() == want
-    if dist is not None:
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(t.item())
+    ok = shard.all_true(ok, dist, torch, dev)
 
     if rank == 0:
         in_bytes = S * L * args.steps * world
