@@ -1,0 +1,994 @@
+// EXPERIMENT, NOT BUILT: k_inflate.h with a segment-parallel block body (decode_block_seg).
+// Parity-green on the GPU (42 tests) but slower than the shipped decoder; see DESIGN.md section 7.
+// k_inflate.h -- north-star part (5): batched Inflate, one stream per wavefront, decode
+// tables resident in LDS.
+//
+// Replaces CreateReader (LD:2127-2270), GetHuffmanForDecode (LD:2303-2344),
+// DecodeUntilEndOfBlock (LD:2353-2445), DecompressStoreBlock/FixBlock/DynamicBlock
+// (LD:2450-2615), Inflate (LD:2620-2644) and the framing checks of
+// DecompressDeflateInternal / DecompressZlibInternal (LD:2648-2727).
+//
+// Reader model: the reference refills 4 bytes at a time and returns zero bits past the
+// end of input; ReaderBitlenLeft() = 8*len - bits consumed, whatever the refill pattern.
+// The kernel keeps `consumed` and reproduces the same late exhaustion checks (Q11).
+// The bit-serial state is wave-uniform; lanes cooperate on table construction and on
+// match copies.
+#pragma once
+#include "ldh_common.h"
+
+namespace ldh {
+
+constexpr int kLutBits = 10;
+constexpr int kLutSize = 1 << kLutBits;
+
+struct DecTab {
+  uint16_t lut[kLutSize];  // (sym << 4) | len for codes of <= lut_bits bits; 0 = slow path
+  uint16_t symbols[288];   // puff order: by (length, symbol)
+  uint32_t counts[16];
+  uint32_t offs[16];
+  uint32_t first[16];      // first canonical code of each length
+  uint32_t running[16];
+};
+
+struct InflateArgs {
+  const uint8_t *in;
+  const uint64_t *in_off;   // stream s = in[in_off[s] .. in_off[s+1])            (in_len == nullptr)
+  const uint32_t *in_len;   // or: stream s = in + s*in_stride, in_len[s] bytes  (slots)
+  uint64_t in_stride;
+  uint32_t count;
+  int fmt;
+  const uint8_t *dict;
+  uint32_t dlen;
+  uint32_t dict_adler;
+  uint8_t *out;
+  uint64_t out_stride;
+  uint32_t *out_len;
+  uint32_t *bytes_left;
+  int32_t *status;
+  uint32_t *expect_adler;  // zlib trailer value per stream (checked by k_zlib_check)
+  uint32_t tune;           // experiment switches (LDH_TUNE_INFLATE), 0 in production
+};
+
+struct BitReader {
+  const uint32_t *base;  // 4-byte aligned pointer at or before the stream's first byte
+  uint32_t skip;         // bytes between base and the first byte
+  uint32_t nbytes;       // stream length
+  uint32_t chunk;        // per lane: word chunk_w0 + lane
+  uint32_t chunk_w0;     // uniform: first word index held in `chunk`
+  uint32_t next_w;       // uniform: next word to append to bitbuf
+  uint64_t bitbuf;       // uniform
+  uint32_t bitcnt;       // uniform: valid bits in bitbuf
+  uint64_t consumed;     // uniform: bits consumed from the stream so far
+};
+
+__device__ inline void br_load_chunk(BitReader &R, uint32_t w0, uint32_t lane) {
+  const uint32_t w = w0 + lane;
+  const uint64_t first = (uint64_t)w * 4;            // byte offset from base
+  const uint64_t end = (uint64_t)R.skip + R.nbytes;  // one past the last valid byte
+  uint32_t x = 0;
+  if (first < end) {
+    x = R.base[w];
+    if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
+  }
+  R.chunk = x;
+  R.chunk_w0 = w0;
+}
+__device__ inline void br_refill(BitReader &R, uint32_t lane) {
+  while (R.bitcnt <= 32) {
+    if (R.next_w - R.chunk_w0 >= 64) br_load_chunk(R, R.next_w, lane);
+    const uint32_t idx = __builtin_amdgcn_readfirstlane(R.next_w - R.chunk_w0);
+    const uint32_t word = __builtin_amdgcn_readlane(R.chunk, idx);
+    R.bitbuf |= (uint64_t)word << R.bitcnt;
+    R.bitcnt += 32;
+    R.next_w++;
+  }
+}
+// position the reader at stream byte `byte_pos`
+__device__ inline void br_seek(BitReader &R, uint64_t byte_pos, uint32_t lane) {
+  const uint64_t abs = (uint64_t)R.skip + byte_pos;
+  R.consumed = byte_pos * 8;
+  R.next_w = (uint32_t)(abs >> 2);
+  R.bitbuf = 0;
+  R.bitcnt = 0;
+  br_load_chunk(R, R.next_w, lane);
+  br_refill(R, lane);
+  const uint32_t drop = 8 * (uint32_t)(abs & 3);
+  R.bitbuf >>= drop;
+  R.bitcnt -= drop;
+}
+__device__ inline void br_init(BitReader &R, const uint8_t *p, uint32_t n, uint32_t lane) {
+  const uintptr_t a = (uintptr_t)p;
+  R.base = (const uint32_t *)(a & ~(uintptr_t)3);
+  R.skip = (uint32_t)(a & 3);
+  R.nbytes = n;
+  br_seek(R, 0, lane);
+}
+// ReadBits (LD:2140-2161); n <= 16
+__device__ inline uint32_t br_read(BitReader &R, uint32_t n, uint32_t lane) {
+  br_refill(R, lane);
+  const uint32_t v = (uint32_t)(R.bitbuf & ((1ull << n) - 1ull));
+  R.bitbuf >>= n;
+  R.bitcnt -= n;
+  R.consumed += n;
+  return v;
+}
+__device__ inline int64_t br_left(const BitReader &R) {  // ReaderBitlenLeft (LD:2258-2260)
+  return (int64_t)R.nbytes * 8 - (int64_t)R.consumed;
+}
+__device__ inline void br_align(BitReader &R, uint32_t lane) {  // SkipToByteBoundary (LD:2262-2267)
+  const uint32_t s = (uint32_t)((8 - (R.consumed & 7)) & 7);
+  br_refill(R, lane);
+  R.bitbuf >>= s;
+  R.bitcnt -= s;
+  R.consumed += s;
+}
+
+// GetHuffmanForDecode (LD:2303-2344) over lens[0..nsym) (LDS).  Returns `left`:
+// 0 complete (also when there is no code at all, LD:2312-2314), > 0 incomplete,
+// < 0 over-subscribed.  Called by the whole wavefront (block = one wavefront).
+__device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bitlen, int lut_bits,
+                           uint32_t lane) {
+  if (lane < 16) {
+    T.counts[lane] = 0;
+    T.running[lane] = 0;
+    T.offs[lane] = 0;
+    T.first[lane] = 0;
+  }
+  for (int i = lane; i < kLutSize; i += kWave) T.lut[i] = 0;
+  __syncthreads();
+  for (int base = 0; base < nsym; base += kWave) {
+    const int i = base + (int)lane;
+    if (i < nsym) atomicAdd(&T.counts[lens[i]], 1u);
+  }
+  __syncthreads();
+  if (T.counts[0] == (uint32_t)nsym) return 0;  // no codes: "complete", every decode fails
+  int left = 1;
+  for (int len = 1; len <= max_bitlen; len++) {
+    left = left * 2 - (int)T.counts[len];
+    if (left < 0) return left;
+  }
+  if (lane == 0) {
+    uint32_t off = 0, code = 0;
+    for (int len = 1; len <= 15; len++) {
+      code = (code + (len > 1 ? T.counts[len - 1] : 0u)) << 1;
+      T.first[len] = code;
+      T.offs[len] = off;
+      off += T.counts[len];
+    }
+  }
+  __syncthreads();
+  for (int base = 0; base < nsym; base += kWave) {
+    const int i = base + (int)lane;
+    const uint32_t l = i < nsym ? lens[i] : 0;
+    const bool active = l != 0;
+    unsigned long long mask = __ballot(active);
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+      const unsigned long long bal = __ballot(active && ((l >> bit) & 1));
+      mask &= ((l >> bit) & 1) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (active) {
+      const uint32_t in_len = T.running[l] + rank;
+      T.symbols[T.offs[l] + in_len] = (uint16_t)i;
+      if ((int)l <= lut_bits) {
+        const uint32_t c = T.first[l] + in_len;
+        const uint32_t r = __brev(c) >> (32 - l);
+        for (uint32_t k = r; k < (1u << lut_bits); k += (1u << l)) T.lut[k] = (uint16_t)((i << 4) | l);
+      }
+    }
+    __syncthreads();
+    if (active && rank == 0) T.running[l] += (uint32_t)__popcll(mask);
+    __syncthreads();
+  }
+  return left;
+}
+
+// Decode (LD:2206-2256).  Returns the symbol or -10; consumes its bits.
+__device__ inline int decode_sym(const DecTab &T, int lut_bits, BitReader &R, uint32_t lane) {
+  br_refill(R, lane);
+  const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.lut[R.bitbuf & ((1u << lut_bits) - 1u)]);
+  int sym;
+  uint32_t len;
+  if (e) {
+    sym = (int)(e >> 4);
+    len = e & 15;
+  } else {  // canonical bit-serial walk (puff), also the path of every invalid code
+    uint64_t bits = R.bitbuf;
+    int code = 0, first = 0, index = 0;
+    sym = -10;
+    len = 15;
+    for (int l = 1; l <= 15; l++) {
+      code |= (int)(bits & 1);
+      bits >>= 1;
+      const int count = (int)__builtin_amdgcn_readfirstlane(T.counts[l]);
+      if (code - first < count) {
+        sym = (int)__builtin_amdgcn_readfirstlane((uint32_t)T.symbols[index + (code - first)]);
+        len = (uint32_t)l;
+        break;
+      }
+      index += count;
+      first += count;
+      first <<= 1;
+      code <<= 1;
+    }
+  }
+  R.bitbuf >>= len;
+  R.bitcnt -= len;
+  R.consumed += len;
+  return sym;
+}
+
+struct OutState {
+  uint8_t *out;
+  uint64_t cap;
+  uint64_t opos;     // bytes produced
+  const uint8_t *dict;
+  uint32_t dlen;
+  bool dict_loaded;  // buffer[0] ~= nil (LD:2367)
+};
+
+// One token of DecodeUntilEndOfBlock (LD:2379-2440), wave-uniform ("scalar") form.  Used for
+// tokens the lane-parallel decoder cannot resolve (codes longer than the lookup table, invalid
+// codes).  *eob is set when the token was the end-of-block symbol.
+// The reference's buffer_size only differs from the output position after it reached 65536,
+// where no distance (<= 32768) can fail, so `dist > opos + ext` is the -11 test (LD:2406-2410).
+__device__ int decode_one(const DecTab &LT, const DecTab &DT, int lbits, int dbits, BitReader &R,
+                          OutState &O, uint32_t ext, uint32_t lane, bool *eob) {
+  const int symbol = decode_sym(LT, lbits, R, lane);
+  *eob = symbol == 256;
+  if (symbol < 0 || symbol > 285) return -10;
+  if (symbol < 256) {
+    if (O.opos >= O.cap) return kStatusOutputFull;
+    if (lane == 0) O.out[O.opos] = (uint8_t)symbol;
+    O.opos++;
+  } else if (symbol > 256) {
+    const uint32_t ls = (uint32_t)symbol - 257;
+    uint32_t len;  // LD:188-200 base lengths, computed instead of tabulated
+    if (ls < 8) {
+      len = 3 + ls;
+    } else if (ls == 28) {
+      len = 258;
+    } else {
+      const uint32_t eb = (ls >> 2) - 1;
+      len = 3 + ((4u + (ls & 3)) << eb) + br_read(R, eb, lane);
+    }
+    const int dsym = decode_sym(DT, dbits, R, lane);
+    if (dsym < 0 || dsym > 29) return -10;
+    uint32_t dist;
+    if (dsym < 4) {
+      dist = (uint32_t)dsym + 1;
+    } else {
+      const uint32_t eb = dist_extra_bits((uint32_t)dsym);
+      dist = 1 + ((2u + ((uint32_t)dsym & 1)) << eb) + br_read(R, eb, lane);
+    }
+    if ((uint64_t)dist > O.opos + ext) return -11;
+    if (O.opos + len > O.cap) return kStatusOutputFull;
+    // bytes this wave stored earlier must be visible to the loads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int64_t src0 = (int64_t)O.opos - (int64_t)dist;
+    for (uint32_t k = lane; k < len; k += kWave) {
+      const uint32_t j = dist >= len ? k : (k % dist);
+      const int64_t si = src0 + j;
+      const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+      O.out[O.opos + k] = byte;
+    }
+    O.opos += len;
+  }
+  if (br_left(R) < 0) return 2;  // LD:2428
+  return 0;
+}
+
+__device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lane) {
+  br_seek(R, bit_pos >> 3, lane);
+  const uint32_t drop = (uint32_t)(bit_pos & 7);
+  R.bitbuf >>= drop;
+  R.bitcnt -= drop;
+  R.consumed = bit_pos;
+}
+
+// DecodeUntilEndOfBlock (LD:2353-2445), lane-parallel.
+// The scalar unit, not the vector lanes, bounded the wave-uniform decoder (every branch and
+// every uniform bit operation is a scalar instruction, one per cycle per CU).  Here lane k
+// decodes, speculatively, the token that would start k bits after the current position
+// (table lookups are per-lane LDS gathers); walking next[k] = k + token_bits from lane 0
+// then picks the real tokens of this 64-bit window (about eight per round).  Literals are
+// stored by their lanes at once.  A match whose source is older than everything in flight
+// is loaded at once (one lane per byte) and stored a round later, so that the load latency
+// overlaps the next round's decode; matches that read recent output are copied in order.
+// Tokens the tables cannot resolve fall back to decode_one.
+__device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
+                            uint32_t *s_in /* LDS, 64 dwords */, uint32_t tune) {
+  uint32_t ext = 0;
+  if (O.dict && !O.dict_loaded) {  // LD:2367-2377
+    ext = O.dlen;
+    O.dict_loaded = true;
+  }
+  const uint64_t nbits = (uint64_t)R.nbytes * 8;
+  const uint64_t skip_bits = (uint64_t)R.skip * 8;
+  uint64_t bp = R.consumed;        // bits consumed so far (uniform)
+  uint32_t cw0 = 0xFFFFFFFFu;      // first dword (relative to R.base) held in s_in
+  // match copies in flight: bytes loaded in one round are stored in the next
+  constexpr int kPend = 4;
+  uint32_t pend_n = 0, pval[kPend] = {0, 0, 0, 0}, plen[kPend] = {0, 0, 0, 0};
+  uint64_t pdst[kPend] = {0, 0, 0, 0};
+  for (;;) {
+    const uint64_t absbit = skip_bits + bp;
+    const uint32_t dw = (uint32_t)(absbit >> 5);
+    if (cw0 == 0xFFFFFFFFu || dw < cw0 || dw + 6 >= cw0 + 64) {
+      __syncthreads();
+      cw0 = dw;
+      const uint64_t first = ((uint64_t)cw0 + lane) * 4;
+      const uint64_t end = (uint64_t)R.skip + R.nbytes;
+      uint32_t x = 0;
+      if (first < end) {
+        x = R.base[cw0 + lane];
+        if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
+      }
+      s_in[lane] = x;
+      __syncthreads();
+    }
+    // ---- every lane decodes the token starting `lane` bits ahead
+    const uint32_t bit = (uint32_t)(absbit - (uint64_t)cw0 * 32) + lane;
+    const uint32_t di = bit >> 5, sh = bit & 31;
+    const uint32_t w0 = s_in[di], w1 = s_in[di + 1], w2 = s_in[di + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const uint64_t win = ((uint64_t)hi << 32) | lo;
+    const uint32_t e = LT.lut[lo & (kLutSize - 1)];
+    const uint32_t sym = e >> 4, l1 = e & 15;
+    const bool is_lit = sym < 256, is_eob = sym == 256, is_len = sym > 256;
+    bool slow = e == 0;
+    bool bad = sym > 285;
+    const uint32_t ls = is_len ? (sym > 285 ? 28u : sym - 257) : 0u;
+    const uint32_t leb = (ls < 8 || ls == 28) ? 0u : (ls >> 2) - 1;
+    const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4u + (ls & 3)) << leb));
+    const uint32_t mlen = lbase + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
+    const uint32_t t = l1 + leb;
+    const uint32_t din = (uint32_t)(win >> t);
+    const uint32_t e2 = DT.lut[din & (kLutSize - 1)];
+    const uint32_t dsym = e2 >> 4, l2 = e2 & 15;
+    slow = slow | (is_len & (e2 == 0));
+    bad = bad | (is_len & (dsym > 29));
+    const uint32_t dsc = dsym > 29 ? 29u : dsym;
+    const uint32_t deb = dsc < 4 ? 0u : (dsc >> 1) - 1;
+    const uint32_t dbase = dsc < 4 ? dsc + 1 : 1 + ((2u + (dsc & 1)) << deb);
+    const uint32_t dist = dbase + ((din >> l2) & ((1u << deb) - 1u));
+    const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
+    const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
+
+    // ---- walk the chain of real tokens from lane 0; my_off = output offset of each.
+    // A token the walk cannot pass (slow / invalid / end of block) advances by 64.
+    const bool hard = slow | bad | is_eob;
+    const uint32_t P = hard ? 64u : (tok_bits | (out_len << 8));
+    unsigned long long valid = 0;
+    uint32_t k = 0, run = 0, my_off = 0;
+    do {
+      const uint32_t p = __builtin_amdgcn_readlane(P, k);
+      valid |= 1ull << k;
+      my_off = lane == k ? run : my_off;
+      run += p >> 8;
+      k += p & 0xff;
+    } while (k < 64);
+    const bool is_tok = (valid >> lane) & 1;
+    // ---- stop events, in the reference's order of checks for one token
+    const uint64_t my_pos = O.opos + my_off;
+    const bool err11 = is_len & ((uint64_t)dist > my_pos + ext);            // LD:2406-2410
+    const bool full = my_pos + out_len > O.cap;
+    const bool exh = bp + lane + tok_bits > nbits;                          // LD:2428
+    const unsigned long long stops = __ballot(is_tok & (hard | err11 | full | exh));
+    const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
+    const bool commit = is_tok & (lane < first);
+    // ---- copies deferred by the previous round: their loads have had a whole round to land
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // every store issued before this point is complete: all output below `fenced` is readable
+    const uint64_t fenced = pend_n ? pdst[0] : O.opos;
+#pragma unroll
+    for (int q = 0; q < kPend; q++)
+      if (q < (int)pend_n && lane < plen[q]) O.out[pdst[q] + lane] = (uint8_t)pval[q];
+    pend_n = 0;
+    // ---- literals of this round
+    if (commit & is_lit) O.out[my_pos] = (uint8_t)sym;
+    // ---- matches of this round
+    const bool cm = commit & is_len;
+    unsigned long long mm = __ballot(cm);
+    if (mm) {
+      // a match whose source [dst-dist, dst-dist+len) lies wholly below `fenced` depends on
+      // nothing in flight (this also excludes every self-overlapping match, dist < len)
+      const bool near = cm & (my_pos + mlen > fenced + dist);
+      if (__ballot(near) == 0) {
+        do {
+          const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+          mm &= mm - 1;
+          const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+          const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+          const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
+          const int64_t src0 = (int64_t)dst - (int64_t)d;
+          if (len <= kWave && pend_n < kPend) {  // load now, store in the next round
+            const int64_t si = src0 + lane;
+            const uint8_t *sp = si < 0 ? O.dict + ((int64_t)O.dlen + si) : O.out + si;
+            // (one load per slot, written straight into the slot's register: a select on the
+            // loaded value would make the wave wait for it here)
+#pragma unroll
+            for (int q = 0; q < kPend; q++)
+              if (q == (int)pend_n) {
+                if (lane < len) pval[q] = *sp;
+                plen[q] = len;
+                pdst[q] = dst;
+              }
+            pend_n++;
+          } else {
+            for (uint32_t i = lane; i < len; i += kWave) {
+              const int64_t si = src0 + i;
+              const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+              O.out[dst + i] = byte;
+            }
+          }
+        } while (mm);
+      } else {
+        // in order, each one seeing everything stored before it
+        do {
+          const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+          mm &= mm - 1;
+          const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+          const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+          const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const int64_t src0 = (int64_t)dst - (int64_t)d;
+          for (uint32_t i = lane; i < len; i += kWave) {
+            const uint32_t jj = d >= len ? i : (i % d);
+            const int64_t si = src0 + jj;
+            const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+            O.out[dst + i] = byte;
+          }
+        } while (mm);
+      }
+    }
+    if (first == 64) {  // the whole window was consumed
+      O.opos += run;
+      bp += k;
+      continue;
+    }
+    // ---- a stop: nothing may stay deferred past this round
+    if (pend_n) {
+#pragma unroll
+      for (int q = 0; q < kPend; q++)
+        if (q < (int)pend_n && lane < plen[q]) O.out[pdst[q] + lane] = (uint8_t)pval[q];
+      pend_n = 0;
+    }
+    // ---- the stopping token
+    const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
+                        (exh ? 16u : 0u) | (is_eob ? 32u : 0u);
+    const uint32_t f = __builtin_amdgcn_readlane(fl, first);
+    O.opos += __builtin_amdgcn_readlane(my_off, first);
+    bp += first;
+    if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
+      br_seek_bits(R, bp, lane);
+      bool eob = false;
+      const int st = decode_one(LT, DT, kLutBits, kLutBits, R, O, ext, lane, &eob);
+      if (st != 0) return st;
+      if (eob) return 0;
+      bp = R.consumed;
+      continue;
+    }
+    R.consumed = bp;
+    if (f & 2) return -10;
+    if (f & 4) return -11;
+    if (f & 8) return kStatusOutputFull;
+    bp += __builtin_amdgcn_readlane(tok_bits, first);
+    R.consumed = bp;
+    if (f & 16) return 2;
+    // end of block: hand the position back to the wave-uniform reader
+    br_seek_bits(R, bp, lane);
+    return 0;
+  }
+}
+
+// ------------------------------------------------------------------ segment-parallel block body
+// The round-based decoder above spends 64 lanes on 64 bit offsets to find ~5 tokens.  Here
+// every lane decodes its own stretch of the block, token after token, and the lanes are then
+// reconciled (Huffman streams re-synchronise: a decoder started at a wrong bit falls onto
+// real token boundaries after a few tokens):
+//   A. lane k decodes from bit k*S of the super-round to the end of its segment and marks the
+//      starts of its tokens in a bitmap (lane 0 starts at a real token, the others guess);
+//   B. lane k decodes on into segment k+1 until it lands on a start marked by lane k+1: if
+//      lane k was on real tokens, lane k+1 is from there on.  Lanes are valid up to the first
+//      one that does not meet its neighbour (or ends on end-of-block / something irregular);
+//   C. valid lanes count the bytes of their stretch (prefix sum -> where each lane writes);
+//   D. valid lanes assemble the output of the super-round in an LDS buffer with one "is there"
+//      bit per byte: literals at once, a match as soon as the part of its source that lies in
+//      the buffer is there (LDS operations of a wave complete in order, so no fence is needed
+//      between lanes; the lowest waiting match always has its source, so the loop ends); the
+//      part of a source below the super-round comes from memory.  The buffer is then copied out
+//      with aligned 4-byte stores.
+// Anything irregular (code the tables cannot resolve at all, invalid symbol, -11, output
+// full, input exhausted, little input left) is not handled here: the super-round is cut
+// before it, or dropped, and decode_block -- the exact decoder -- takes over from a token
+// boundary.  Returns 0: block finished (reader placed after the end-of-block code);
+// 1: go on with decode_block at R.consumed.
+constexpr uint32_t kSegBits = 512;
+constexpr uint32_t kObuf = 8192;  // bytes of output assembled per super-round
+constexpr uint32_t kSegWords = kSegBits / 32;
+constexpr uint32_t kStageWords = kWave * kSegWords + 96;
+// staged word i lives at i + i / kSegWords: lanes read kSegWords apart, and an odd stride spreads
+// them over the LDS banks (unpadded, 64 lanes hit 2 banks)
+constexpr uint32_t kStagePhys = kStageWords + kStageWords / kSegWords + 1;
+__device__ inline uint32_t stage_at(uint32_t i) { return i + i / kSegWords; }
+
+struct LaneTok {
+  uint32_t bits;  // length of the token in the stream
+  uint32_t kind;  // 0 literal (a = byte), 1 match (a = length, b = distance), 2 end of block, 3 irregular
+  uint32_t a, b;
+};
+
+// Decode (LD:2206-2256) for one lane: table lookup, canonical bit-serial walk for longer codes.
+// Returns false for a code that does not exist.
+__device__ inline bool lane_sym(const DecTab &T, uint32_t bits, uint32_t *sym, uint32_t *len) {
+  const uint32_t e = T.lut[bits & (kLutSize - 1)];
+  if (e) {
+    *sym = e >> 4;
+    *len = e & 15;
+    return true;
+  }
+  uint32_t code = 0, first = 0, index = 0;
+  for (uint32_t l = 1; l <= 15; l++) {
+    code |= bits & 1;
+    bits >>= 1;
+    const uint32_t count = T.counts[l];
+    if (code - first < count) {  // (code >= first always)
+      *sym = T.symbols[index + (code - first)];
+      *len = l;
+      return true;
+    }
+    index += count;
+    first = (first + count) << 1;
+    code <<= 1;
+  }
+  return false;
+}
+
+// one token at bit `pos` of the staged input (LD:2379-2427); nbits_left = stream bits from pos on
+__device__ inline LaneTok lane_token(const DecTab &LT, const DecTab &DT, const uint32_t *stage, uint32_t stage_off,
+                                     uint32_t pos, int64_t nbits_left) {
+  LaneTok t{0, 3, 0, 0};
+  const uint32_t bit = stage_off + pos, di = bit >> 5, sh = bit & 31;
+  if (di + 2 >= kStageWords) return t;  // beyond what was staged
+  const uint32_t w0 = stage[stage_at(di)], w1 = stage[stage_at(di + 1)], w2 = stage[stage_at(di + 2)];
+  const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+  const uint64_t win = ((uint64_t)hi << 32) | lo;
+  uint32_t sym, l1;
+  if (!lane_sym(LT, lo, &sym, &l1)) return t;
+  if (sym < 256) {
+    t.kind = 0;
+    t.a = sym;
+    t.bits = l1;
+  } else if (sym == 256) {
+    t.kind = 2;
+    t.bits = l1;
+  } else {
+    if (sym > 285) return t;
+    const uint32_t ls = sym - 257;
+    const uint32_t leb = (ls < 8 || ls == 28) ? 0u : (ls >> 2) - 1;
+    const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4u + (ls & 3)) << leb));
+    const uint32_t mlen = lbase + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
+    const uint32_t tb = l1 + leb;
+    const uint32_t din = (uint32_t)(win >> tb);
+    uint32_t dsym, l2;
+    if (!lane_sym(DT, din, &dsym, &l2)) return t;
+    if (dsym > 29) return t;
+    const uint32_t deb = dsym < 4 ? 0u : (dsym >> 1) - 1;
+    const uint32_t dbase = dsym < 4 ? dsym + 1 : 1 + ((2u + (dsym & 1)) << deb);
+    t.kind = 1;
+    t.a = mlen;
+    t.b = dbase + ((din >> l2) & ((1u << deb) - 1u));
+    t.bits = tb + l2 + deb;
+  }
+  if ((int64_t)t.bits > nbits_left) t.kind = 3;  // LD:2428: left to the exact decoder
+  return t;
+}
+
+__device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
+                                uint32_t *stage /* LDS, kStageWords */, uint32_t *bm /* LDS, kSegWords * 64 */, uint32_t *ob /* LDS, kObuf/4 + 2 */,
+                                uint32_t *wbm /* LDS, kObuf/32 */, uint32_t *dbg) {
+  const uint32_t ext = (O.dict && !O.dict_loaded) ? O.dlen : 0u;  // LD:2367-2377
+  const uint64_t nbits = (uint64_t)R.nbytes * 8;
+  const uint64_t skip_bits = (uint64_t)R.skip * 8;
+  uint64_t bp = R.consumed;
+  for (;;) {
+    R.consumed = bp;
+    if (bp + 4 * kSegBits > nbits) return 1;  // the tail of a stream is not worth a super-round
+    // ---- stage the input of the super-round; clear the bitmaps
+    const uint64_t absbit = skip_bits + bp;
+    const uint32_t w0i = (uint32_t)(absbit >> 5);
+    const uint32_t stage_off = (uint32_t)(absbit & 31);
+    __syncthreads();
+    {
+      const uint64_t end = (uint64_t)R.skip + R.nbytes;
+      for (uint32_t i = lane; i < kStageWords; i += kWave) {
+        const uint64_t first = ((uint64_t)w0i + i) * 4;
+        uint32_t x = 0;
+        if (first < end) {
+          x = R.base[w0i + i];
+          if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
+        }
+        stage[stage_at(i)] = x;
+      }
+#pragma unroll
+      for (uint32_t w = 0; w < kSegWords; w++) bm[w * kWave + lane] = 0;
+    }
+    __syncthreads();
+    const int64_t left0 = (int64_t)(nbits - bp);  // stream bits from the super-round's start on
+
+    // ---- A: own segment
+    const uint32_t seg0 = lane * kSegBits, seg1 = seg0 + kSegBits;
+    uint32_t pos = seg0;
+    uint32_t endkind = 0;  // 0 ran to the end of the segment, 2 end of block, 3 irregular
+    while (pos < seg1) {
+      const uint32_t rel = pos - seg0;
+      bm[(rel >> 5) * kWave + lane] |= 1u << (rel & 31);
+      const LaneTok t = lane_token(LT, DT, stage, stage_off, pos, left0 - (int64_t)pos);
+      if (t.kind >= 2) {
+        endkind = t.kind;
+        break;
+      }
+      pos += t.bits;
+    }
+    __syncthreads();
+    // ---- B: on into the next segment until a start of its lane is met
+    // fin = where this lane's stretch ends if the lane is valid: the meeting point, or the token at
+    // which it stopped (end of block: fin is that token; irregular / nothing met: a token boundary)
+    bool synced = false;
+    uint32_t fin = pos;
+    if (endkind == 0 && lane < kWave - 1) {
+      for (;;) {
+        const uint32_t rel = pos - seg1;
+        if (rel >= kSegBits) break;  // passed the whole neighbour without meeting it
+        if ((bm[(rel >> 5) * kWave + lane + 1] >> (rel & 31)) & 1) {
+          synced = true;
+          break;
+        }
+        const LaneTok t = lane_token(LT, DT, stage, stage_off, pos, left0 - (int64_t)pos);
+        if (t.kind >= 2) {
+          endkind = t.kind;
+          break;
+        }
+        pos += t.bits;
+      }
+      fin = pos;
+    }
+    // ---- valid lanes: 0 .. first lane that did not meet its neighbour
+    const unsigned long long syncm = __ballot(synced);
+    const uint32_t kt = (uint32_t)__builtin_ctzll(~syncm);  // (lane 63 never syncs: kt <= 63)
+    bool valid = lane <= kt;
+    uint32_t st = __shfl_up(fin, 1);
+    if (lane == 0) st = 0;
+    uint32_t t_kind = __builtin_amdgcn_readlane(endkind, kt);
+    uint32_t t_fin = __builtin_amdgcn_readlane(fin, kt);
+    if (t_fin == 0) return 1;  // nothing decodable at the very first token
+    dbg[0]++; dbg[1] += kt + 1; dbg[2] += t_fin; dbg[3] += t_kind == 3; dbg[4] += t_kind == 2;
+
+    // ---- C: bytes each valid lane will write
+    uint32_t nb = 0;
+    if (valid) {
+      uint32_t p = st;
+      while (p < fin) {
+        const LaneTok t = lane_token(LT, DT, stage, stage_off, p, left0 - (int64_t)p);
+        nb += t.kind == 0 ? 1u : t.a;
+        p += t.bits;
+      }
+    }
+    uint32_t incl = nb;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off);
+      if (lane >= (uint32_t)off) incl += u;
+    }
+    uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total > kObuf) {  // keep the lanes whose output fits the assembly buffer
+      const uint32_t nfit = (uint32_t)__popcll(__ballot(valid && incl <= kObuf));
+      if (nfit == 0) return 1;
+      valid = lane < nfit;
+      total = __builtin_amdgcn_readlane(incl, nfit - 1);
+      t_kind = 0;
+      t_fin = __builtin_amdgcn_readlane(fin, nfit - 1);
+    }
+    if (O.opos + total > O.cap) return 1;  // the exact decoder finds the token that does not fit
+
+    // ---- D: assemble the super-round's output in LDS.  wbm has one bit per byte that is there.
+    for (uint32_t i = lane; i < kObuf / 32; i += kWave) wbm[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // what is below O.opos in memory is complete
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __syncthreads();
+    uint8_t *ob8 = (uint8_t *)ob;
+    uint32_t orel = incl - nb;  // where this lane writes next, relative to O.opos
+    uint32_t p = st;
+    bool done = !valid || p >= fin;
+    bool bad = false;
+    LaneTok t{0, 0, 0, 0};
+    bool have = false;  // t is the token at p (a waiting lane does not decode it again)
+    while (__ballot(!done)) {
+      dbg[5]++;
+      if (!done && !have) {
+        t = lane_token(LT, DT, stage, stage_off, p, left0 - (int64_t)p);
+        have = true;
+      }
+      if (!done && t.kind == 0) {
+        ob8[orel] = (uint8_t)t.a;
+        atomicOr(&wbm[orel >> 5], 1u << (orel & 31));
+        orel++;
+        p += t.bits;
+        have = false;
+        if (p >= fin) done = true;
+      } else if (!done) {
+        const uint32_t len = t.a, d = t.b;
+        if ((uint64_t)d > O.opos + orel + ext) {  // LD:2406-2410: the exact decoder reports it
+          bad = true;
+          done = true;
+        } else {
+          // source = bytes [a0, b0) relative to O.opos, repeated with period d if it runs into the
+          // destination; what lies below 0 is finished output in memory (or the dictionary), the
+          // rest must already be in the buffer
+          const int32_t a0 = (int32_t)orel - (int32_t)d;
+          const int32_t b0 = a0 + (int32_t)(len < d ? len : d);
+          bool ready = true;
+          if (b0 > 0) {
+            const uint32_t ra = a0 > 0 ? (uint32_t)a0 : 0u, rb = (uint32_t)b0;
+            for (uint32_t w = ra >> 5; w <= (rb - 1) >> 5; w++) {
+              const uint32_t lo = w * 32 < ra ? ra - w * 32 : 0u;
+              const uint32_t hi = rb < w * 32 + 32 ? rb - w * 32 : 32u;  // bits [lo, hi)
+              const uint32_t mask = (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+              if ((wbm[w] & mask) != mask) ready = false;
+            }
+          }
+          if (ready) {
+            if (b0 <= 0) {  // all of it from memory: 16 loads in flight, then 16 LDS stores
+              const int64_t s0 = (int64_t)O.opos + a0;
+              uint32_t j = 0;
+              for (uint32_t i0 = 0; i0 < len; i0 += 16) {
+                uint8_t tmp[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                  const int64_t si = s0 + j;
+                  const uint8_t *sp = si < 0 ? O.dict + ((int64_t)O.dlen + si) : O.out + si;
+                  tmp[k] = i0 + k < len ? *sp : (uint8_t)0;
+                  j = j + 1 == d ? 0 : j + 1;  // (wraps only for a match at the very start of the buffer)
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++)
+                  if (i0 + k < len) ob8[orel + i0 + k] = tmp[k];
+              }
+            } else if (a0 >= 0) {  // all of it in the buffer
+              uint32_t j = 0;
+              for (uint32_t i = 0; i < len; i++) {
+                ob8[orel + i] = ob8[(uint32_t)a0 + j];
+                j = j + 1 == d ? 0 : j + 1;
+              }
+            } else {  // straddles the start of the super-round
+              uint32_t j = 0;
+              for (uint32_t i = 0; i < len; i++) {
+                const int32_t r = a0 + (int32_t)j;
+                uint8_t byte;
+                if (r >= 0) {
+                  byte = ob8[r];
+                } else {
+                  const int64_t si = (int64_t)O.opos + r;
+                  byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+                }
+                ob8[orel + i] = byte;
+                j = j + 1 == d ? 0 : j + 1;
+              }
+            }
+            for (uint32_t w = orel >> 5; w <= (orel + len - 1) >> 5; w++) {
+              const uint32_t lo = w * 32 < orel ? orel - w * 32 : 0u;
+              const uint32_t hi = orel + len < w * 32 + 32 ? orel + len - w * 32 : 32u;
+              atomicOr(&wbm[w], (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u));
+            }
+            orel += len;
+            p += t.bits;
+            have = false;
+            if (p >= fin) done = true;
+          }
+        }
+      }
+    }
+    if (__ballot(bad)) return 1;  // nothing of this super-round has reached memory
+    __syncthreads();
+    {  // buffer -> memory: bytes up to the first 4-byte boundary of the destination, dwords, bytes
+      uint8_t *g = O.out + O.opos;
+      uint32_t head = (uint32_t)((4 - ((uintptr_t)g & 3)) & 3);
+      if (head > total) head = total;
+      if (lane < head) g[lane] = ob8[lane];
+      const uint32_t ndw = (total - head) / 4;
+      for (uint32_t i = lane; i < ndw; i += kWave) {
+        const uint32_t off = head + 4 * i;
+        const uint32_t x = __builtin_amdgcn_alignbyte(ob[(off >> 2) + 1], ob[off >> 2], off & 3);
+        *(uint32_t *)(g + off) = x;
+      }
+      const uint32_t done_b = head + 4 * ndw;
+      if (lane < total - done_b) g[done_b + lane] = ob8[done_b + lane];
+    }
+    O.opos += total;
+    bp += t_fin;
+    if (t_kind == 2) {  // the end-of-block code itself
+      const LaneTok t = lane_token(LT, DT, stage, stage_off, t_fin, left0 - (int64_t)t_fin);
+      const uint32_t eb = __builtin_amdgcn_readfirstlane(t.bits);
+      bp += eb;
+      O.dict_loaded = O.dict_loaded || O.dict != nullptr;
+      br_seek_bits(R, bp, lane);
+      return 0;
+    }
+    if (t_kind == 3) {
+      R.consumed = bp;
+      return 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
+  __shared__ DecTab LT, DT;
+  __shared__ uint8_t lens[320 + 32];
+  __shared__ uint32_t s_in[kWave + 4];
+  __shared__ uint32_t s_stage[kStagePhys];
+  __shared__ uint32_t s_bm[kSegWords * kWave];
+  __shared__ uint32_t s_ob[kObuf / 4 + 2];
+  __shared__ uint32_t s_wbm[kObuf / 32];
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
+  const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
+  BitReader R;
+  br_init(R, A.in + off, n, lane);
+  OutState O;
+  O.out = A.out + (size_t)s * A.out_stride;
+  O.cap = A.out_stride;
+  O.opos = 0;
+  O.dict = A.dict;
+  O.dlen = A.dlen;
+  O.dict_loaded = false;
+
+  int status = 0;
+  uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t expect = 0;
+  int fixed_ready = 0;
+  do {
+    if (A.fmt == 1) {  // LD:2664-2704
+      const uint32_t cmf = br_read(R, 8, lane);
+      if (br_left(R) < 0) { status = 2; break; }
+      if ((cmf & 15) != 8) { status = -12; break; }
+      if ((cmf >> 4) > 7) { status = -13; break; }
+      const uint32_t flg = br_read(R, 8, lane);
+      if (br_left(R) < 0) { status = 2; break; }
+      if ((cmf * 256 + flg) % 31 != 0) { status = -14; break; }
+      if ((flg >> 5) & 1) {
+        if (!A.dict) { status = -16; break; }
+        uint32_t ad = 0;
+        for (int k = 0; k < 4; k++) ad = (ad << 8) | br_read(R, 8, lane);
+        if (br_left(R) < 0) { status = 2; break; }
+        if (ad != A.dict_adler) { status = -17; break; }
+      }
+    }
+    bool last = false;
+    while (!last && status == 0) {  // LD:2620-2638
+      last = br_read(R, 1, lane) == 1;
+      const uint32_t type = br_read(R, 2, lane);
+      if (type == 0) {  // LD:2450-2491
+        br_align(R, lane);
+        const uint32_t len = br_read(R, 16, lane);
+        if (br_left(R) < 0) { status = 2; break; }
+        const uint32_t comp = br_read(R, 16, lane);
+        if (br_left(R) < 0) { status = 2; break; }
+        if ((len & 255) + (comp & 255) != 255 || (len >> 8) + (comp >> 8) != 255) { status = -2; break; }
+        if (br_left(R) < (int64_t)len * 8) { status = 2; break; }  // ReadBytes: out of input
+        if (O.opos + len > O.cap) { status = kStatusOutputFull; break; }
+        const uint64_t ipos = R.consumed >> 3;
+        const uint8_t *src = A.in + off + ipos;
+        for (uint32_t k = lane; k < len; k += kWave) O.out[O.opos + k] = src[k];
+        O.opos += len;
+        br_seek(R, ipos + len, lane);
+      } else if (type == 1) {  // LD:2496-2501
+        if (fixed_ready != 1) {
+          for (int i = lane; i < 288; i += kWave) lens[i] = (uint8_t)fixed_lit_bits(i);
+          if (lane < 32) lens[288 + lane] = 5;
+          __syncthreads();
+          build_table(LT, lens, 288, 9, kLutBits, lane);
+          build_table(DT, lens + 288, 32, 5, kLutBits, lane);
+          fixed_ready = 1;
+        }
+        status = 0;
+        if ((A.tune & 8) || decode_block_seg(LT, DT, R, O, lane, s_stage, s_bm, s_ob, s_wbm, dbg) != 0)
+          status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
+      } else if (type == 2) {  // LD:2506-2615
+        fixed_ready = 0;
+        const uint32_t nlen = br_read(R, 5, lane) + 257;
+        const uint32_t ndist = br_read(R, 5, lane) + 1;
+        const uint32_t ncode = br_read(R, 4, lane) + 4;
+        if (nlen > 286 || ndist > 30) { status = -3; break; }
+        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        __syncthreads();
+        if (lane < 19) lens[lane] = 0;
+        __syncthreads();
+        for (uint32_t i = 0; i < ncode; i++) {
+          const uint32_t v = br_read(R, 3, lane);
+          if (lane == 0) lens[order[i]] = (uint8_t)v;
+        }
+        __syncthreads();
+        if (build_table(DT, lens, 19, 7, 7, lane) != 0) { status = -4; break; }
+        __syncthreads();
+        for (int i = lane; i < 320; i += kWave) lens[i] = 0;
+        __syncthreads();
+        uint32_t index = 0;
+        uint32_t prev_len = 0;  // lens[index-1], tracked in a register
+        while (index < nlen + ndist) {
+          int symbol = decode_sym(DT, 7, R, lane);
+          if (symbol < 0) { status = symbol; break; }
+          if (symbol < 16) {
+            if (lane == 0) lens[index] = (uint8_t)symbol;
+            prev_len = (uint32_t)symbol;
+            index++;
+          } else {
+            uint32_t bitlen = 0, rep;
+            if (symbol == 16) {
+              if (index == 0) { status = -5; break; }
+              bitlen = prev_len;
+              rep = 3 + br_read(R, 2, lane);
+            } else if (symbol == 17) {
+              rep = 3 + br_read(R, 3, lane);
+            } else {
+              rep = 11 + br_read(R, 7, lane);
+            }
+            if (index + rep > nlen + ndist) { status = -6; break; }
+            for (uint32_t k = lane; k < rep; k += kWave) lens[index + k] = (uint8_t)bitlen;
+            prev_len = bitlen;
+            index += rep;
+          }
+        }
+        if (status != 0) break;
+        __syncthreads();
+        if (lens[256] == 0) { status = -9; break; }
+        // the distance lengths follow the nlen literal/length lengths; move them apart
+        const uint8_t dl = lane < ndist ? lens[nlen + lane] : 0;
+        __syncthreads();
+        if (lane < 32) lens[320 + lane] = dl;
+        __syncthreads();
+        int err = build_table(LT, lens, (int)nlen, 15, kLutBits, lane);
+        if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
+        err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
+        if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
+        status = 0;
+        if ((A.tune & 8) || decode_block_seg(LT, DT, R, O, lane, s_stage, s_bm, s_ob, s_wbm, dbg) != 0)
+          status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
+      } else {
+        status = -1;
+      }
+    }
+    if (status != 0) break;
+    if (A.fmt == 1) {  // LD:2707-2722 (the Adler comparison itself is k_zlib_check)
+      br_align(R, lane);
+      for (int k = 0; k < 4; k++) expect = (expect << 8) | br_read(R, 8, lane);
+      if (br_left(R) < 0) { status = 2; break; }
+    }
+  } while (false);
+
+  if ((A.tune & 16) && s == 0 && lane == 0)
+    printf("seg: rounds %u lanes %u bits %u irregular %u eob %u Diters %u\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]);
+  if (lane == 0) {
+    const int64_t left = br_left(R);
+    A.status[s] = status;
+    A.out_len[s] = (uint32_t)O.opos;
+    A.bytes_left[s] = (status == 0 && left > 0) ? (uint32_t)(left / 8) : 0u;
+    if (A.expect_adler) A.expect_adler[s] = expect;
+  }
+}
+
+// DecompressZlibInternal's final comparison (LD:2717-2722)
+__global__ void k_zlib_check(uint32_t count, const uint32_t *expect, const uint32_t *actual,
+                             int32_t *status) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= count) return;
+  if (status[s] == 0 && expect[s] != actual[s]) status[s] = -15;
+}
+
+}  // namespace ldh

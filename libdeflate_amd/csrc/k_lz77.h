@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     if (V_LDS) *(uint32_t *)(ldsV + w) = word;
   }
   __syncthreads();
-  if (nv == 0) return;
+  if (nv == 0 || !B.need_lz) return;  // (stored blocks and huffman_only need V only)
 
   for (int pass = 0; pass < 3; pass++) {
     const uint32_t shift = 2 - pass;  // digit of v is V[v + shift]

@@ -241,6 +241,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.bufB = (uint32_t *)g_bufB.p;
     B.bufC = greedy ? (uint32_t *)g_bufC.p : nullptr;
     B.want_rank = greedy ? 1u : 0u;
+    B.need_lz = need_lz ? 1u : 0u;
     B.blocks = (BlockInfo *)g_blocks.p;
     B.adler = (uint32_t *)g_adler.p;
     B.out = d_out + s0 * out_stride;
@@ -261,7 +262,6 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
     }
     // V (and, for the match search, the trigram chains)
-    // TODO(round 2): skip the sort for level 0 / huffman_only (only V is needed there)
     if ((size_t)nvp + kVPad <= kSortLdsMaxV)
       LAUNCH("k_sort_links", k_sort_links<true>, c, kSortThreads, (nvp + kVPad + 15) & ~15u, B);
     else

@@ -15,15 +15,24 @@ def pytest_configure(config):
     so = os.path.join(ROOT, "oracle", "libld_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libld_oracle.so"])
+    _gpu_present()
+
+
+_GPU = None
 
 
 def _gpu_present():
-    try:
-        import torch
+    # Cached, and asked for before any test module is imported: torch ships its own HIP runtime, and
+    # the runtime that libdeflate_hip.so links finds no device when torch's is initialised after it.
+    global _GPU
+    if _GPU is None:
+        try:
+            import torch
 
-        return torch.cuda.is_available()
-    except Exception:
-        return False
+            _GPU = bool(torch.cuda.is_available())
+        except Exception:
+            _GPU = False
+    return _GPU
 
 
 def pytest_collection_modifyitems(config, items):
