@@ -134,6 +134,34 @@ def test_synthetic_configs(B):
             assert g == o_compress(s, level=level), level
 
 
+def test_large_streams(LD, B):
+    # streams whose virtual buffer does not fit LDS (the sort's global-memory variant), many deflate blocks,
+    # matches at the far edge of the window, long runs; with and without a dictionary; round trip on the GPU too
+    rng = np.random.default_rng(11)
+    base = golden("totalrp3.txt") + golden("encode_6bit_weakaura.txt") + golden("item_strings.txt")
+    blob = bytes(rng.integers(0, 256, 40000, dtype=np.uint8))
+    cases = [
+        (base * 6)[:400001],
+        blob[:32768] * 9,                        # period exactly the window size
+        blob[:32769] * 5,                        # one byte beyond it: no match may be found across periods
+        b"a" * 300000,
+        (b"abcdefgh" * 5000 + blob[:7000]) * 5,
+        base[:140000] + blob + base[:140000],
+    ]
+    dct = golden("dictionary32768.txt")
+    d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
+    for level in (1, 3, 5, 6):
+        got = B.compress_batch(cases, level=level)
+        for s, g in zip(cases, got):
+            assert g == o_compress(s, level=level), (level, len(s))
+        back = B.decompress_batch([c for c, _ in got], max_out=max(len(c) for c in cases))
+        assert [x for x, _ in back] == cases
+    for level in (2, 5):
+        got = B.compress_batch(cases[:2] + cases[4:], fmt=1, level=level, dictionary=d)
+        for s, g in zip(cases[:2] + cases[4:], got):
+            assert g == o_compress(s, zlib=True, level=level, dict=dct), (level, len(s))
+
+
 def test_no_dependence_on_stale_buffers(B):
     cases = _small() + _files()
     os.environ["LDH_POISON"] = "1"
