@@ -134,6 +134,29 @@ int ldh_print6_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, s
                                 uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
                                 uint8_t *d_ok);
 
+/* ---- CreateCodec and the WoW channel codecs -----------------------
+ * LibDeflate:CreateCodec(reserved_chars, escape_chars, map_chars) (LD:2921-3056).  Returns NULL
+ * and sets *err to the reference's second return value ("No escape characters supplied." ...) when
+ * the codec cannot be created; the type check and its usage error stay in the shim.
+ * EncodeForWoWAddonChannel / ChatChannel (LD:3058-3158) are this with the reference's fixed
+ * arguments ("\000","\001","" and LD:3118-3124). */
+typedef struct ldh_codec ldh_codec;
+ldh_codec *ldh_codec_create(const uint8_t *reserved, size_t nr, const uint8_t *escape, size_t ne,
+                            const uint8_t *map, size_t nm, const char **err);
+void ldh_codec_free(ldh_codec *c);
+/* codec:Encode (LD:3030-3037); out_stride >= 2 * longest stream (and % 16 == 0). */
+int ldh_codec_encode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off,
+                           size_t count, uint8_t *out_base, size_t out_stride, uint32_t *out_len);
+int ldh_codec_encode_batch_dev(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off,
+                               size_t count, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len);
+/* codec:Decode (LD:3042-3053); ok[s] = 0 stands for nil; out_stride >= longest stream. */
+int ldh_codec_decode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off,
+                           size_t count, uint8_t *out_base, size_t out_stride, uint32_t *out_len,
+                           uint8_t *ok);
+int ldh_codec_decode_batch_dev(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off,
+                               size_t count, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
+                               uint8_t *d_ok);
+
 /* ---- measurement support (bench.py) -------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the library
  * stream; ldh_profile_get returns the accumulated milliseconds and launch count of one

@@ -104,6 +104,8 @@ class _LibDeflate(object):
     _VERSION = "1.0.2-release"
     _MAJOR = "LibDeflate"
     _MINOR = 3
+    _addon = None  # the two lazily built codec caches (LibDeflate.lua:3058, 3126)
+    _chat = None
 
     # -- LibDeflate.lua:401-442
     def Adler32(self, s):
@@ -242,6 +244,79 @@ class _LibDeflate(object):
         if not ok.value:
             return None
         return bytes(out[: ol.value])
+
+    # ---- CreateCodec and the WoW channel codecs (LibDeflate.lua:2921-3158) ----------------------
+
+    def CreateCodec(self, reserved_chars, escape_chars, map_chars):
+        """(codec, None), or (None, message) exactly as the reference's two return values."""
+        for v in (reserved_chars, escape_chars, map_chars):
+            if not isinstance(v, (bytes, bytearray)):
+                raise UsageError("Usage: LibDeflate:CreateCodec(reserved_chars, escape_chars, map_chars):"
+                                 " All arguments must be string.")
+        N.init()
+        err = C.c_char_p()
+        h = N.lib.ldh_codec_create(_buf(reserved_chars), len(reserved_chars), _buf(escape_chars), len(escape_chars),
+                                   _buf(map_chars), len(map_chars), C.byref(err))
+        if not h:
+            return None, err.value.decode()
+        return Codec(h), None
+
+    def _addon_codec(self):
+        if self._addon is None:  # LibDeflate.lua:3060-3062
+            self._addon, _ = self.CreateCodec(b"\000", b"\001", b"")
+        return self._addon
+
+    def _chat_codec(self):
+        if self._chat is None:  # LibDeflate.lua:3118-3124
+            self._chat, _ = self.CreateCodec(b"sS\000\012\015\174%" + bytes(range(128, 256)), b"\035\037", b"\017\024")
+        return self._chat
+
+    def _channel(self, name, codec, s, decode):
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError("Usage: LibDeflate:%s(str): 'str' - string expected got '%s'." % (name, _lua_type(s)))
+        return codec.Decode(s) if decode else codec.Encode(s)
+
+    def EncodeForWoWAddonChannel(self, s=None):
+        return self._channel("EncodeForWoWAddonChannel", self._addon_codec(), s, False)
+
+    def DecodeForWoWAddonChannel(self, s=None):
+        return self._channel("DecodeForWoWAddonChannel", self._addon_codec(), s, True)
+
+    def EncodeForWoWChatChannel(self, s=None):
+        return self._channel("EncodeForWoWChatChannel", self._chat_codec(), s, False)
+
+    def DecodeForWoWChatChannel(self, s=None):
+        return self._channel("DecodeForWoWChatChannel", self._chat_codec(), s, True)
+
+
+class Codec(object):
+    """The table CreateCodec returns: Encode(str) and Decode(str) (nil -> None)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                N.lib.ldh_codec_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def Encode(self, s=None):
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError("Usage: codec:Encode(str): 'str' - string expected got '%s'." % _lua_type(s))
+        from . import batch
+        return batch.codec_encode_batch(self, [bytes(s)])[0]
+
+    def Decode(self, s=None):
+        if not isinstance(s, (bytes, bytearray)):
+            raise UsageError("Usage: codec:Decode(str): 'str' - string expected got '%s'." % _lua_type(s))
+        from . import batch
+        return batch.codec_decode_batch(self, [bytes(s)])[0]
 
 
 LibDeflate = _LibDeflate()

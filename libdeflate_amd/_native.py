@@ -37,6 +37,12 @@ _SIGS = {
     "ldh_decompress": (C.c_int, [u8p, sz, C.c_int, C.c_void_p, u8p, sz, C.POINTER(sz), C.POINTER(sz),
                                  C.POINTER(C.c_int)]),
     "ldh_adler32": (C.c_int, [u8p, sz, C.POINTER(C.c_uint32)]),
+    "ldh_codec_create": (C.c_void_p, [u8p, sz, u8p, sz, u8p, sz, C.POINTER(C.c_char_p)]),
+    "ldh_codec_free": (None, [C.c_void_p]),
+    "ldh_codec_encode_batch": (C.c_int, [C.c_void_p, u8p, u64p, sz, u8p, sz, u32p]),
+    "ldh_codec_encode_batch_dev": (C.c_int, [C.c_void_p, u8p, u64p, sz, u8p, sz, u32p]),
+    "ldh_codec_decode_batch": (C.c_int, [C.c_void_p, u8p, u64p, sz, u8p, sz, u32p, u8p]),
+    "ldh_codec_decode_batch_dev": (C.c_int, [C.c_void_p, u8p, u64p, sz, u8p, sz, u32p, u8p]),
     "ldh_print6_encode": (C.c_int, [u8p, sz, u8p, sz, C.POINTER(sz)]),
     "ldh_print6_decode": (C.c_int, [u8p, sz, u8p, sz, C.POINTER(sz), C.POINTER(C.c_int)]),
     "ldh_compress_batch": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_int, C.c_int, C.c_void_p, u8p, sz, u32p, u8p]),

@@ -114,6 +114,37 @@ def print6_decode_batch(strings):
     return [out[i * stride: i * stride + int(out_len[i])].tobytes() if ok[i] else None for i in range(n)]
 
 
+def codec_encode_batch(codec, strings):
+    """codec:Encode for every string (codec: LibDeflate.CreateCodec result)."""
+    N.init()
+    n = len(strings)
+    if n == 0:
+        return []
+    data, off = _concat(strings)
+    stride = (2 * max(len(s) for s in strings) + 31) // 16 * 16
+    out = np.empty(n * stride, dtype=np.uint8)
+    out_len = np.zeros(n, dtype=np.uint32)
+    N.check(N.lib.ldh_codec_encode_batch(codec.handle(), data.ctypes.data, off.ctypes.data, n, out.ctypes.data,
+                                         stride, out_len.ctypes.data))
+    return [out[i * stride: i * stride + int(out_len[i])].tobytes() for i in range(n)]
+
+
+def codec_decode_batch(codec, strings):
+    """codec:Decode for every string; None stands for nil."""
+    N.init()
+    n = len(strings)
+    if n == 0:
+        return []
+    data, off = _concat(strings)
+    stride = (max(len(s) for s in strings) + 31) // 16 * 16
+    out = np.empty(n * stride, dtype=np.uint8)
+    out_len = np.zeros(n, dtype=np.uint32)
+    ok = np.zeros(n, dtype=np.uint8)
+    N.check(N.lib.ldh_codec_decode_batch(codec.handle(), data.ctypes.data, off.ctypes.data, n, out.ctypes.data,
+                                         stride, out_len.ctypes.data, ok.ctypes.data))
+    return [out[i * stride: i * stride + int(out_len[i])].tobytes() if ok[i] else None for i in range(n)]
+
+
 class DeviceBatch(object):
     """A batch of streams resident in HBM: `data` (uint8 torch tensor on cuda) holds the
     streams back to back, `off` (int64 tensor on cuda, count+1) their offsets."""

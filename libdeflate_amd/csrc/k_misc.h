@@ -190,4 +190,152 @@ __global__ __launch_bounds__(kP6Threads) void k_print6_decode(const uint8_t *in,
   }
 }
 
+
+// ------------------------------------------------------------------ CreateCodec codecs
+// LibDeflate:CreateCodec (LD:2921-3056) and, through it, Encode/DecodeForWoWAddonChannel / ChatChannel
+// (LD:3058-3158).  The Lua closure's gsub tables become byte tables in device memory:
+struct CodecTables {
+  uint8_t enc_len[256];  // 1: byte (possibly mapped) -> enc0;  2: escape byte enc0 + suffix enc1
+  uint8_t enc0[256], enc1[256];
+  uint8_t reserved[256];   // decode_fail_pattern (LD:3040)
+  uint8_t map_back[256];   // first decode gsub (identity where nothing is mapped)
+  uint8_t pass_escape[256];
+  uint32_t npass;
+  uint32_t pad_;
+  uint16_t pass_dec[1][256];  // npass tables: suffix -> original byte, 0xFFFF = not in the set
+};
+
+constexpr int kCodecThreads = 256;
+constexpr uint32_t kCodecPer = 16;  // consecutive bytes per thread per tile
+
+__device__ inline uint32_t codec_block_scan(uint32_t val, uint32_t tid, uint32_t *s_w, uint32_t *tile_total) {
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint32_t inc = val;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= (uint32_t)off) inc += t;
+  }
+  __syncthreads();  // s_w of the tile before has been read
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < kCodecThreads / kWave; w++) {
+    if (w < wave) base += s_w[w];
+    tot += s_w[w];
+  }
+  *tile_total = tot;
+  return base + inc - val;
+}
+
+// codec:Encode (LD:3030-3037): one gsub that replaces every byte to translate by one or two bytes.
+// One workgroup per stream; expansion is compacted with a scan per 4096-byte tile.
+__global__ __launch_bounds__(kCodecThreads) void k_codec_encode(const uint8_t *in, const uint64_t *in_off,
+                                                               const CodecTables *T, uint8_t *out,
+                                                               uint64_t out_stride, uint32_t *out_len) {
+  __shared__ uint32_t s_w[kCodecThreads / kWave];
+  const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  const uint8_t *p = in + in_off[s];
+  const uint64_t n = in_off[s + 1] - in_off[s];
+  uint8_t *o = out + (uint64_t)s * out_stride;
+  uint64_t obase = 0;
+  for (uint64_t t0 = 0; t0 < n; t0 += kCodecThreads * kCodecPer) {
+    const uint64_t j0 = t0 + (uint64_t)tid * kCodecPer;
+    uint8_t b[kCodecPer];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kCodecPer; k++) {
+      b[k] = j0 + k < n ? p[j0 + k] : (uint8_t)0;
+      cnt += j0 + k < n ? T->enc_len[b[k]] : 0u;
+    }
+    uint32_t tot;
+    uint64_t w = obase + codec_block_scan(cnt, tid, s_w, &tot);
+#pragma unroll
+    for (uint32_t k = 0; k < kCodecPer; k++)
+      if (j0 + k < n) {
+        o[w++] = T->enc0[b[k]];
+        if (T->enc_len[b[k]] == 2) o[w++] = T->enc1[b[k]];
+      }
+    obase += tot;
+  }
+  if (tid == 0) out_len[s] = (uint32_t)obase;
+}
+
+// codec:Decode (LD:3042-3053): nil if a reserved byte is present; then one gsub per pass over the
+// whole string.  A launch is one pass: pass 0 reads the input (through the single-byte translate of
+// the optional first gsub, which is per byte and can be applied on the fly), later passes read the
+// previous pass's slots.  "escape + suffix" matches cannot overlap (the escape byte is never a
+// suffix), so whether a byte starts a pair, or is the second byte of one, is decided locally.
+__global__ __launch_bounds__(kCodecThreads) void k_codec_decode_pass(const uint8_t *in, const uint64_t *in_off,
+                                                                    const uint8_t *prev, const uint32_t *prev_len,
+                                                                    uint64_t stride, const CodecTables *T,
+                                                                    uint32_t pass, uint8_t *out, uint32_t *out_len,
+                                                                    uint8_t *ok) {
+  __shared__ uint32_t s_w[kCodecThreads / kWave];
+  __shared__ uint32_t s_bad;
+  const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  const bool first = pass == 0;
+  const uint8_t *p = first ? in + in_off[s] : prev + (uint64_t)s * stride;
+  const uint64_t n = first ? in_off[s + 1] - in_off[s] : prev_len[s];
+  uint8_t *o = out + (uint64_t)s * stride;
+  if (first) {
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    uint32_t bad = 0;
+    for (uint64_t j = tid; j < n; j += kCodecThreads) bad |= T->reserved[p[j]];
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (s_bad) {  // LD:3048
+      if (tid == 0) {
+        ok[s] = 0;
+        out_len[s] = 0;
+      }
+      return;
+    }
+    if (tid == 0) ok[s] = 1;
+  } else if (!ok[s]) {
+    if (tid == 0) out_len[s] = 0;
+    return;
+  }
+  const uint8_t E = T->pass_escape[pass];
+  const uint16_t *dec = T->pass_dec[pass];
+  uint64_t obase = 0;
+  for (uint64_t t0 = 0; t0 < n; t0 += kCodecThreads * kCodecPer) {
+    const uint64_t j0 = t0 + (uint64_t)tid * kCodecPer;
+    // bytes j0-1 .. j0+kCodecPer (one before, one after), through the single-byte translate in pass 0
+    uint8_t b[kCodecPer + 2];
+#pragma unroll
+    for (uint32_t k = 0; k < kCodecPer + 2; k++) {
+      const uint64_t j = j0 + k;  // index + 1
+      uint8_t x = 0;
+      if (j >= 1 && j - 1 < n) {
+        x = p[j - 1];
+        if (first) x = T->map_back[x];
+      }
+      b[k] = x;
+    }
+    uint8_t val[kCodecPer];
+    uint32_t keepm = 0, cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kCodecPer; k++) {
+      const uint64_t j = j0 + k;
+      const uint8_t x = b[k + 1];
+      const bool starts = j + 1 < n && x == E && dec[b[k + 2]] != 0xFFFF;
+      const bool second = j >= 1 && b[k] == E && dec[x] != 0xFFFF;
+      val[k] = starts ? (uint8_t)dec[b[k + 2]] : x;
+      if (j < n && !second) {
+        keepm |= 1u << k;
+        cnt++;
+      }
+    }
+    uint32_t tot;
+    uint64_t w = obase + codec_block_scan(cnt, tid, s_w, &tot);
+#pragma unroll
+    for (uint32_t k = 0; k < kCodecPer; k++)
+      if ((keepm >> k) & 1) o[w++] = val[k];
+    obase += tot;
+  }
+  if (tid == 0) out_len[s] = (uint32_t)obase;
+}
+
 }  // namespace ldh

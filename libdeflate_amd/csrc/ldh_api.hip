@@ -27,6 +27,11 @@ struct ldh_dict {
   uint32_t adler;
 };
 
+struct ldh_codec {
+  ldh::CodecTables *d_tab;  // device copy: header + npass suffix tables
+  uint32_t npass;
+};
+
 namespace {
 
 std::mutex g_mu;
@@ -41,7 +46,7 @@ struct DevBuf {
 // workspace (grow-only)
 DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_bufC, g_blocks, g_adler, g_misc32a, g_misc32b;
 // staging for the host-pointer entry points
-DevBuf g_h_in, g_h_off, g_h_out, g_h_len, g_h_aux8, g_h_aux32a, g_h_aux32b;
+DevBuf g_h_in, g_h_off, g_h_out, g_h_len, g_h_aux8, g_h_aux32a, g_h_aux32b, g_codec_tmp;
 
 // last compress batch (for ldh_debug_fetch)
 Batch g_last{};
@@ -371,7 +376,7 @@ void ldh_shutdown(void) {
   if (g_device < 0) return;
   hipStreamSynchronize(g_stream);
   for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_bufC, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
-                    &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b}) {
+                    &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b, &g_codec_tmp}) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
@@ -719,6 +724,198 @@ int ldh_adler32(const uint8_t *s, size_t n, uint32_t *adler) {
   const uint64_t off[2] = {0, n};
   static const uint8_t empty = 0;
   return ldh_adler32_batch(s ? s : &empty, off, 1, adler);
+}
+
+// ---- CreateCodec codecs (LD:2921-3158) ------------------------------------------
+ldh_codec *ldh_codec_create(const uint8_t *reserved, size_t nr, const uint8_t *escape, size_t ne,
+                            const uint8_t *map, size_t nm, const char **err) {
+  static const char *kDup =
+      "There must be no duplicate characters in the concatenation of reserved_chars, escape_chars and map_chars.";
+  const char *dummy;
+  if (!err) err = &dummy;
+  *err = nullptr;
+  if (ne == 0) { *err = "No escape characters supplied."; return nullptr; }  // LD:2928
+  if (nr < nm) {                                                             // LD:2929-2932
+    *err = "The number of reserved characters must be at least as many as the number of mapped chars.";
+    return nullptr;
+  }
+  if (nr == 0) { *err = "No characters to encode."; return nullptr; }        // LD:2933
+  std::vector<uint8_t> all;
+  all.insert(all.end(), reserved, reserved + nr);
+  all.insert(all.end(), escape, escape + ne);
+  all.insert(all.end(), map, map + nm);
+  bool taken[256] = {false}, done[256] = {false};
+  for (uint8_t b : all) {  // LD:2937-2946
+    if (taken[b]) { *err = kDup; return nullptr; }
+    taken[b] = true;
+  }
+  // host image: header, then one suffix table per escape character that gets used
+  std::vector<uint16_t> dec(256, 0xFFFF);
+  std::vector<std::vector<uint16_t>> passes;
+  ldh::CodecTables H;
+  memset(&H, 0, sizeof(H));
+  for (int b = 0; b < 256; b++) {
+    H.enc_len[b] = 1;
+    H.enc0[b] = (uint8_t)b;
+    H.map_back[b] = (uint8_t)b;
+  }
+  for (size_t i = 0; i < nr; i++) H.reserved[reserved[i]] = 1;  // LD:3040
+  for (size_t i = 0; i < nm; i++) {                             // LD:2957-2971
+    H.enc0[reserved[i]] = map[i];
+    done[reserved[i]] = true;
+    H.map_back[map[i]] = reserved[i];
+  }
+  size_t esc = 0;
+  int r = 0;
+  for (size_t i = 0; i < all.size(); i++) {  // LD:2981-3022
+    const uint8_t ch = all[i];
+    if (!done[ch]) {
+      while (r >= 256 || taken[r]) {
+        r++;
+        if (r > 255) {  // this escape character's suffixes are used up
+          H.pass_escape[passes.size()] = escape[esc];
+          passes.push_back(dec);
+          dec.assign(256, 0xFFFF);
+          esc++;
+          r = 0;
+          if (esc >= ne) { *err = "Out of escape characters."; return nullptr; }  // LD:2999-3005
+        }
+      }
+      H.enc_len[ch] = 2;
+      H.enc0[ch] = escape[esc];
+      H.enc1[ch] = (uint8_t)r;
+      done[ch] = true;
+      dec[r] = ch;
+      r++;
+    }
+    if (i + 1 == all.size()) {
+      H.pass_escape[passes.size()] = escape[esc];
+      passes.push_back(dec);
+    }
+  }
+  H.npass = (uint32_t)passes.size();
+
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (check_init()) { *err = "libdeflate_hip is not initialised"; return nullptr; }
+  const size_t head = offsetof(ldh::CodecTables, pass_dec);
+  const size_t bytes = head + passes.size() * 512;
+  std::vector<uint8_t> img(bytes);
+  memcpy(img.data(), &H, head);
+  for (size_t k = 0; k < passes.size(); k++) memcpy(img.data() + head + k * 512, passes[k].data(), 512);
+  ldh_codec *c = new ldh_codec{nullptr, H.npass};
+  if (hipMalloc((void **)&c->d_tab, bytes) != hipSuccess ||
+      hipMemcpy(c->d_tab, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    if (c->d_tab) hipFree(c->d_tab);
+    delete c;
+    *err = "hipMalloc/hipMemcpy of the codec tables failed";
+    fail(LDH_E_NOMEM, "%s", *err);
+    return nullptr;
+  }
+  return c;
+}
+
+void ldh_codec_free(ldh_codec *c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (c->d_tab) hipFree(c->d_tab);
+  delete c;
+}
+
+namespace {
+int codec_decode_dev_locked(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                            uint8_t *d_out, size_t out_stride, uint32_t *d_out_len, uint8_t *d_ok) {
+  // one launch per gsub pass, ping-pong between the caller's slots and a scratch copy of them so
+  // that the last pass lands in the caller's
+  if (int rc = ensure(g_codec_tmp, count * out_stride + 64)) return rc;
+  if (int rc = ensure(g_misc32a, count * 4 + 64)) return rc;
+  uint8_t *tmp = (uint8_t *)g_codec_tmp.p;
+  uint32_t *tmp_len = (uint32_t *)g_misc32a.p;
+  const uint8_t *prev = nullptr;
+  const uint32_t *prev_len = nullptr;
+  for (uint32_t p = 0; p < c->npass; p++) {
+    const bool to_out = ((c->npass - 1 - p) & 1) == 0;
+    uint8_t *dst = to_out ? d_out : tmp;
+    uint32_t *dst_len = to_out ? d_out_len : tmp_len;
+    LAUNCH("k_codec_decode_pass", k_codec_decode_pass, (uint32_t)count, kCodecThreads, 0, d_in, d_in_off, prev,
+           prev_len, (uint64_t)out_stride, (const CodecTables *)c->d_tab, p, dst, dst_len, d_ok);
+    prev = dst;
+    prev_len = dst_len;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int ldh_codec_encode_batch_dev(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                               uint8_t *d_out, size_t out_stride, uint32_t *d_out_len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!c) return fail(LDH_E_ARG, "codec is null");
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  LAUNCH("k_codec_encode", k_codec_encode, (uint32_t)count, kCodecThreads, 0, d_in, d_in_off,
+         (const CodecTables *)c->d_tab, d_out, (uint64_t)out_stride, d_out_len);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ldh_codec_decode_batch_dev(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                               uint8_t *d_out, size_t out_stride, uint32_t *d_out_len, uint8_t *d_ok) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!c) return fail(LDH_E_ARG, "codec is null");
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  return codec_decode_dev_locked(c, d_in, d_in_off, count, d_out, out_stride, d_out_len, d_ok);
+}
+
+int ldh_codec_encode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                           uint8_t *out_base, size_t out_stride, uint32_t *out_len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!c) return fail(LDH_E_ARG, "codec is null");
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  for (size_t s = 0; s < count; s++)
+    if ((in_off[s + 1] - in_off[s]) * 2 > out_stride)
+      return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
+  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
+  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
+  LAUNCH("k_codec_encode", k_codec_encode, (uint32_t)count, kCodecThreads, 0, (const uint8_t *)g_h_in.p,
+         (const uint64_t *)g_h_off.p, (const CodecTables *)c->d_tab, (uint8_t *)g_h_out.p, (uint64_t)out_stride,
+         (uint32_t *)g_h_len.p);
+  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+int ldh_codec_decode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                           uint8_t *out_base, size_t out_stride, uint32_t *out_len, uint8_t *ok) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (int rc = check_init()) return rc;
+  if (!c) return fail(LDH_E_ARG, "codec is null");
+  if (!count) return 0;
+  if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  for (size_t s = 0; s < count; s++)
+    if (in_off[s + 1] - in_off[s] > out_stride)
+      return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
+  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
+  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
+  if (int rc = ensure(g_h_aux8, count + 64)) return rc;
+  if (int rc = codec_decode_dev_locked(c, (const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, count,
+                                       (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
+                                       (uint8_t *)g_h_aux8.p))
+    return rc;
+  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(ok, g_h_aux8.p, count, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return 0;
 }
 
 int ldh_print6_encode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {

@@ -2,7 +2,7 @@
 
 Drop-in for require("LibDeflate") on the hot path only: CompressDeflate / CompressZlib /
 Compress*WithDict / DecompressDeflate / DecompressZlib / Decompress*WithDict / Adler32 /
-CreateDictionary / EncodeForPrint / DecodeForPrint.  Argument validation and the usage-error
+CreateDictionary / EncodeForPrint / DecodeForPrint / CreateCodec / the WoW channel codecs.  Argument validation and the usage-error
 strings are kept in Lua exactly as the reference words them; everything after validation goes
 through the C ABI of include/libdeflate_hip.h.  The batched entry point is returned as a SECOND
 value of require (the reference's TestExported demands exactly its 22 keys on the first table).
@@ -24,6 +24,14 @@ int ldh_decompress(const uint8_t *in, size_t n, int fmt, const ldh_dict *dict, u
 int ldh_adler32(const uint8_t *s, size_t n, uint32_t *adler);
 int ldh_print6_encode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
 int ldh_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, int *ok);
+typedef struct ldh_codec ldh_codec;
+ldh_codec *ldh_codec_create(const uint8_t *reserved, size_t nr, const uint8_t *escape, size_t ne,
+                            const uint8_t *map, size_t nm, const char **err);
+void ldh_codec_free(ldh_codec *c);
+int ldh_codec_encode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                           uint8_t *out_base, size_t out_stride, uint32_t *out_len);
+int ldh_codec_decode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off, size_t count,
+                           uint8_t *out_base, size_t out_stride, uint32_t *out_len, uint8_t *ok);
 int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt, int level,
                        int strategy, const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
                        uint32_t *out_len, uint8_t *pad_bits);
@@ -194,6 +202,67 @@ function LibDeflate:DecodeForPrint(str)
   check(C.ldh_print6_decode(str, #str, out, cap, ol, ok))
   if ok[0] == 0 then return nil end
   return ffi.string(out, ol[0])
+end
+
+-- CreateCodec and the WoW channel codecs (reference :2921-3158): tables live in the library
+function LibDeflate:CreateCodec(reserved_chars, escape_chars, map_chars)
+  if type(reserved_chars) ~= "string" or type(escape_chars) ~= "string" or type(map_chars) ~= "string" then
+    error("Usage: LibDeflate:CreateCodec(reserved_chars," .. " escape_chars, map_chars):" ..
+            " All arguments must be string.", 2)
+  end
+  local err = ffi.new("const char *[1]")
+  local h = C.ldh_codec_create(reserved_chars, #reserved_chars, escape_chars, #escape_chars, map_chars, #map_chars, err)
+  if h == nil then return nil, ffi.string(err[0]) end
+  h = ffi.gc(h, C.ldh_codec_free)
+  local codec = {}
+  local function run(str, decode)
+    local off = ffi.new("uint64_t[2]", 0, #str)
+    local stride = math.floor(((decode and #str or 2 * #str) + 31) / 16) * 16
+    local out, ol, ok = ffi.new("uint8_t[?]", stride), ffi.new("uint32_t[1]"), ffi.new("uint8_t[1]")
+    if decode then
+      check(C.ldh_codec_decode_batch(h, str, off, 1, out, stride, ol, ok))
+      if ok[0] == 0 then return nil end
+    else
+      check(C.ldh_codec_encode_batch(h, str, off, 1, out, stride, ol))
+    end
+    return ffi.string(out, ol[0])
+  end
+  function codec:Encode(str)
+    if type(str) ~= "string" then
+      error(("Usage: codec:Encode(str):" .. " 'str' - string expected got '%s'."):format(type(str)), 2)
+    end
+    return run(str, false)
+  end
+  function codec:Decode(str)
+    if type(str) ~= "string" then
+      error(("Usage: codec:Decode(str):" .. " 'str' - string expected got '%s'."):format(type(str)), 2)
+    end
+    return run(str, true)
+  end
+  return codec
+end
+local _addon_codec, _chat_codec
+local function addon_codec()
+  _addon_codec = _addon_codec or LibDeflate:CreateCodec("\000", "\001", "")
+  return _addon_codec
+end
+local function chat_codec()
+  if not _chat_codec then
+    local r = {}
+    for i = 128, 255 do r[#r + 1] = string.char(i) end
+    _chat_codec = LibDeflate:CreateCodec("sS\000\010\013\124%" .. table.concat(r), "\029\031", "\015\020")
+  end
+  return _chat_codec
+end
+for name, spec in pairs({EncodeForWoWAddonChannel = {addon_codec, "Encode"}, DecodeForWoWAddonChannel = {addon_codec, "Decode"},
+                         EncodeForWoWChatChannel = {chat_codec, "Encode"}, DecodeForWoWChatChannel = {chat_codec, "Decode"}}) do
+  LibDeflate[name] = function(_, str)
+    if type(str) ~= "string" then
+      error(("Usage: LibDeflate:" .. name .. "(str):" .. " 'str' - string expected got '%s'."):format(type(str)), 2)
+    end
+    local codec = spec[1]()
+    return codec[spec[2]](codec, str)
+  end
 end
 
 -- Batched entry point (second return value of require): list of strings in, list of results out.

@@ -1417,3 +1417,110 @@ int ldo_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len
   *out_len = o;
   return 0;
 }
+
+
+/* ======================================================================= CreateCodec */
+
+/* LD:2921-3056.  The pattern strings of the reference are replaced by what they denote: sets of
+ * bytes and translate tables; gsub's left-to-right, non-overlapping scan is kept literally. */
+int ldo_codec_build(const uint8_t *reserved, size_t nr, const uint8_t *escape, size_t ne,
+                    const uint8_t *map, size_t nm, ldo_codec *c, const char **err) {
+  static const char *e_noesc = "No escape characters supplied.";
+  static const char *e_count = "The number of reserved characters must be at least as many as the number of mapped chars.";
+  static const char *e_none = "No characters to encode.";
+  static const char *e_dup = "There must be no duplicate characters in the concatenation of reserved_chars, escape_chars and map_chars.";
+  static const char *e_out = "Out of escape characters.";
+  *err = NULL;
+  if (ne == 0) { *err = e_noesc; return -1; }              /* LD:2928 */
+  if (nr < nm) { *err = e_count; return -1; }              /* LD:2929-2932 */
+  if (nr == 0) { *err = e_none; return -1; }               /* LD:2933 */
+  size_t nall = nr + ne + nm;
+  uint8_t *all = (uint8_t *)malloc(nall ? nall : 1);
+  if (!all) { *err = "out of memory"; return -1; }
+  memcpy(all, reserved, nr);
+  memcpy(all + nr, escape, ne);
+  memcpy(all + nr + ne, map, nm);
+  int taken[256] = {0}, translated[256] = {0};
+  for (size_t i = 0; i < nall; i++) {                      /* LD:2937-2946 */
+    if (taken[all[i]]) { free(all); *err = e_dup; return -1; }
+    taken[all[i]] = 1;
+  }
+  memset(c, 0, sizeof(*c));
+  for (int b = 0; b < 256; b++) {
+    c->enc_len[b] = 1;
+    c->enc0[b] = (uint8_t)b;
+    c->map_back[b] = (uint8_t)b;
+    for (int p = 0; p < 256; p++) c->pass_dec[p][b] = 0xFFFF;
+  }
+  for (size_t i = 0; i < nr; i++) c->reserved[reserved[i]] = 1;   /* LD:3040 */
+  if (nm > 0) {                                            /* LD:2957-2971 */
+    c->has_map = 1;
+    for (size_t i = 0; i < nm; i++) {
+      c->enc0[reserved[i]] = map[i];
+      translated[reserved[i]] = 1;
+      c->map_back[map[i]] = reserved[i];
+    }
+  }
+  size_t esc_index = 0;                                    /* LD:2973-2977 */
+  int r = 0;
+  for (size_t i = 0; i < nall; i++) {                      /* LD:2981-3022 */
+    const uint8_t ch = all[i];
+    if (!translated[ch]) {
+      while (r >= 256 || taken[r]) {
+        r++;
+        if (r > 255) {                                     /* switch to the next escape char */
+          c->pass_escape[c->npass++] = escape[esc_index];
+          esc_index++;
+          r = 0;
+          if (esc_index >= ne) { free(all); *err = e_out; return -1; }   /* LD:2999-3005 */
+        }
+      }
+      c->enc_len[ch] = 2;
+      c->enc0[ch] = escape[esc_index];
+      c->enc1[ch] = (uint8_t)r;
+      translated[ch] = 1;
+      c->pass_dec[c->npass][r] = ch;
+      r++;
+    }
+    if (i + 1 == nall) c->pass_escape[c->npass++] = escape[esc_index];   /* LD:3016-3021 */
+  }
+  free(all);
+  return 0;
+}
+
+size_t ldo_codec_encode(const ldo_codec *c, const uint8_t *in, size_t n, uint8_t *out) {  /* LD:3030-3037 */
+  size_t o = 0;
+  for (size_t i = 0; i < n; i++) {
+    out[o++] = c->enc0[in[i]];
+    if (c->enc_len[in[i]] == 2) out[o++] = c->enc1[in[i]];
+  }
+  return o;
+}
+
+int ldo_codec_decode(const ldo_codec *c, const uint8_t *in, size_t n, uint8_t *out, size_t *out_len) {  /* LD:3042-3053 */
+  for (size_t i = 0; i < n; i++)
+    if (c->reserved[in[i]]) return -1;                     /* LD:3048 */
+  uint8_t *a = (uint8_t *)malloc(n ? n : 1), *b = (uint8_t *)malloc(n ? n : 1);
+  if (!a || !b) { free(a); free(b); return -1; }
+  size_t len = n;
+  for (size_t i = 0; i < n; i++) a[i] = c->has_map ? c->map_back[in[i]] : in[i];   /* first gsub */
+  for (int p = 0; p < c->npass; p++) {                     /* one gsub per escape character, in order */
+    const uint8_t E = c->pass_escape[p];
+    size_t o = 0, i = 0;
+    while (i < len) {
+      if (a[i] == E && i + 1 < len && c->pass_dec[p][a[i + 1]] != 0xFFFF) {
+        b[o++] = (uint8_t)c->pass_dec[p][a[i + 1]];
+        i += 2;
+      } else {
+        b[o++] = a[i++];
+      }
+    }
+    uint8_t *t = a; a = b; b = t;
+    len = o;
+  }
+  memcpy(out, a, len);
+  *out_len = len;
+  free(a);
+  free(b);
+  return 0;
+}

@@ -63,6 +63,30 @@ int ldo_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t *out_len
 long ldo_tokens(const uint8_t *in, size_t n, int level, const uint8_t *dict,
                 size_t dict_len, uint16_t *tok_len, uint16_t *tok_dist, long cap);
 
+/* ---- CreateCodec (LD:2921-3056) and the two WoW codecs built on it (LD:3058-3158) ----
+ * Test infrastructure like the rest of this file.  The codec is the set of tables the Lua closure
+ * holds: encode_translate (one or two bytes per input byte) and, for Decode, the fail set
+ * (reserved_chars) and the ordered list of gsub passes: an optional single-byte translate, then one
+ * "escape byte + suffix" pass per escape character that was used. */
+typedef struct {
+  uint8_t enc_len[256];      /* 1: byte (possibly mapped) -> enc0; 2: escape enc0 + suffix enc1 */
+  uint8_t enc0[256], enc1[256];
+  uint8_t reserved[256];     /* decode_fail_pattern */
+  int has_map;               /* first decode pass: single-byte translate */
+  uint8_t map_back[256];     /* identity for bytes that are not mapped */
+  int npass;                 /* escape passes */
+  uint8_t pass_escape[256];
+  uint16_t pass_dec[256][256]; /* suffix -> original byte, 0xFFFF = not in the set */
+} ldo_codec;
+
+/* Returns 0 and fills *c, or -1 with *err = the reference's message (second return of CreateCodec). */
+int ldo_codec_build(const uint8_t *reserved, size_t nr, const uint8_t *escape, size_t ne,
+                    const uint8_t *map, size_t nm, ldo_codec *c, const char **err);
+/* codec:Encode; out needs 2n bytes.  Returns the encoded length. */
+size_t ldo_codec_encode(const ldo_codec *c, const uint8_t *in, size_t n, uint8_t *out);
+/* codec:Decode; out needs n bytes.  Returns 0 and *out_len, or -1 for nil. */
+int ldo_codec_decode(const ldo_codec *c, const uint8_t *in, size_t n, uint8_t *out, size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

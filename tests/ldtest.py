@@ -38,8 +38,46 @@ def oracle_lib():
         L.ldo_tokens.restype = _c.c_long
         L.ldo_tokens.argtypes = [_c.c_char_p, _c.c_size_t, _c.c_int, _c.c_char_p, _c.c_size_t,
                                  _c.c_void_p, _c.c_void_p, _c.c_long]
+        L.ldo_codec_build.argtypes = [_c.c_char_p, _c.c_size_t, _c.c_char_p, _c.c_size_t, _c.c_char_p, _c.c_size_t,
+                                      _c.POINTER(OCodec), _c.POINTER(_c.c_char_p)]
+        L.ldo_codec_encode.restype = _c.c_size_t
+        L.ldo_codec_encode.argtypes = [_c.POINTER(OCodec), _c.c_char_p, _c.c_size_t, _c.c_char_p]
+        L.ldo_codec_decode.argtypes = [_c.POINTER(OCodec), _c.c_char_p, _c.c_size_t, _c.c_char_p,
+                                       _c.POINTER(_c.c_size_t)]
         _L = L
     return _L
+
+
+class OCodec(_c.Structure):  # ldo_codec of oracle/ld_oracle.h
+    _fields_ = [("enc_len", _c.c_uint8 * 256), ("enc0", _c.c_uint8 * 256), ("enc1", _c.c_uint8 * 256),
+                ("reserved", _c.c_uint8 * 256), ("has_map", _c.c_int), ("map_back", _c.c_uint8 * 256),
+                ("npass", _c.c_int), ("pass_escape", _c.c_uint8 * 256), ("pass_dec", (_c.c_uint16 * 256) * 256)]
+
+
+def o_codec_build(reserved, escape, mapped):
+    """CreateCodec of the oracle: (codec, None) or (None, message)."""
+    c = OCodec()
+    err = _c.c_char_p()
+    rc = oracle_lib().ldo_codec_build(reserved, len(reserved), escape, len(escape), mapped, len(mapped),
+                                      _c.byref(c), _c.byref(err))
+    return (c, None) if rc == 0 else (None, err.value.decode())
+
+
+def o_codec_encode(c, s):
+    out = _c.create_string_buffer(2 * len(s) + 8)
+    n = oracle_lib().ldo_codec_encode(_c.byref(c), s, len(s), out)
+    return out.raw[:n]
+
+
+def o_codec_decode(c, s):
+    out = _c.create_string_buffer(len(s) + 8)
+    ol = _c.c_size_t()
+    rc = oracle_lib().ldo_codec_decode(_c.byref(c), s, len(s), out, _c.byref(ol))
+    return None if rc != 0 else out.raw[: ol.value]
+
+
+ADDON_CODEC = (b"\000", b"\001", b"")                                                   # LD:3060-3062
+CHAT_CODEC = (b"sS\000\012\015\174%" + bytes(range(128, 256)), b"\035\037", b"\017\024")  # LD:3118-3124
 
 
 def o_adler32(s):

@@ -6,8 +6,8 @@ import zlib
 import numpy as np
 import pytest
 
-from ldtest import (golden, kat, kat_hex, o_adler32, o_compress, o_decompress, o_print6_decode,
-                    o_print6_encode, splitmix64)
+from ldtest import (ADDON_CODEC, CHAT_CODEC, golden, kat, kat_hex, o_adler32, o_codec_build, o_codec_decode,
+                    o_codec_encode, o_compress, o_decompress, o_print6_decode, o_print6_encode, splitmix64)
 
 pytestmark = pytest.mark.gpu
 
@@ -351,3 +351,46 @@ def test_device_resident_api_matches_host_api(B):
     B.sync()
     assert int(status.abs().sum()) == 0 and int(left.sum()) == 0
     assert torch.equal(dout, data)
+
+
+# ------------------------------------------------------------------ CreateCodec codecs
+
+def test_codecs_match_oracle(LD, B):
+    rng = np.random.default_rng(21)
+    specs = [ADDON_CODEC, CHAT_CODEC]
+    for seed in range(12):
+        perm = bytes(np.random.default_rng(seed).permutation(256).astype(np.uint8))
+        nr, ne, nm = (150, 3, 4) if seed % 3 == 0 else (1 + seed, 1 + seed % 3, seed % 2)
+        specs.append((perm[:nr], perm[nr:nr + ne], perm[nr + ne:nr + ne + nm]))
+    comp = o_compress(golden("totalrp3.txt"), level=5)[0]
+    cases = [b"", b"\x00", b"\x01", bytes(range(256)) * 3, comp, bytes(rng.integers(0, 256, 70001, dtype=np.uint8)),
+             bytes(rng.integers(0, 4, 5000, dtype=np.uint8)), b"sS%|\r\n" * 700, b"\x1d" * 4099, b"\x1d\x1f" * 2050]
+    for spec in specs:
+        oc, oerr = o_codec_build(*spec)
+        gc, gerr = LD.CreateCodec(*spec)
+        assert (oc is None) == (gc is None) and oerr == gerr
+        if oc is None:
+            continue
+        enc = B.codec_encode_batch(gc, cases)
+        assert enc == [o_codec_encode(oc, s) for s in cases]
+        assert B.codec_decode_batch(gc, enc) == cases
+        # Decode of arbitrary strings (pairs that are no escape pairs, reserved bytes -> nil, escape at the very end)
+        junk = cases + [e[:-1] for e in enc if e] + [e[:len(e) // 2] + spec[0][:1] + e[len(e) // 2:] for e in enc]
+        assert B.codec_decode_batch(gc, junk) == [o_codec_decode(oc, s) for s in junk]
+
+
+def test_codec_api_surface(LD):
+    assert LD.CreateCodec(b"1", b"", b"2") == (None, "No escape characters supplied.")           # T:2140-2142
+    assert LD.CreateCodec(b"", b"1", b"")[1] == "No characters to encode."                       # T:2147-2149
+    assert LD.CreateCodec(CHAT_CODEC[0], b"\x1d", b"\x0f\x14")[1] == "Out of escape characters."  # T:2168-2170
+    with pytest.raises(Exception, match="All arguments must be string"):                         # T:2457-2469
+        LD.CreateCodec(None, b"", b"")
+    s = golden("item_strings.txt") + bytes(range(256))
+    for enc, dec, bad in ((LD.EncodeForWoWAddonChannel, LD.DecodeForWoWAddonChannel, b"\x00"),
+                          (LD.EncodeForWoWChatChannel, LD.DecodeForWoWChatChannel, b"sS\x00\n\r|%")):
+        e = enc(s)
+        assert not (set(e) & set(bad)) and dec(e) == s
+        assert dec(e[:10] + bad[:1] + e[10:]) is None                                            # T:2108-2136
+    assert LD.EncodeForWoWAddonChannel(b"\x00\x01\x02") == b"\x01\x02\x01\x03\x02"
+    with pytest.raises(Exception, match=r"Usage: LibDeflate:EncodeForWoWChatChannel\(str\): 'str' - string expected got 'nil'"):
+        LD.EncodeForWoWChatChannel()                                                             # T:2490-2492
