@@ -1,5 +1,6 @@
-// EXPERIMENT, NOT BUILT: k_inflate.h with a segment-parallel block body (decode_block_seg).
-// Parity-green on the GPU (42 tests) but slower than the shipped decoder; see DESIGN.md section 7.
+// EXPERIMENT, NOT BUILT: k_inflate.h with a segment-parallel block body (decode_block_seg), second version
+// (token list + 64-tokens-at-a-time assembly in LDS).  Parity-green on the GPU (46 tests) but slower than the
+// shipped decoder in batch mode; see DESIGN.md section 7.
 // k_inflate.h -- north-star part (5): batched Inflate, one stream per wavefront, decode
 // tables resident in LDS.
 //
@@ -497,13 +498,14 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
 //   B. lane k decodes on into segment k+1 until it lands on a start marked by lane k+1: if
 //      lane k was on real tokens, lane k+1 is from there on.  Lanes are valid up to the first
 //      one that does not meet its neighbour (or ends on end-of-block / something irregular);
-//   C. valid lanes count the bytes of their stretch (prefix sum -> where each lane writes);
-//   D. valid lanes assemble the output of the super-round in an LDS buffer with one "is there"
-//      bit per byte: literals at once, a match as soon as the part of its source that lies in
-//      the buffer is there (LDS operations of a wave complete in order, so no fence is needed
-//      between lanes; the lowest waiting match always has its source, so the loop ends); the
-//      part of a source below the super-round comes from memory.  The buffer is then copied out
-//      with aligned 4-byte stores.
+//   C. valid lanes count their bytes and tokens (prefix sums -> where each token goes) and write
+//      the tokens, in stream order, to a list in LDS;
+//   D. the output of the super-round is assembled in an LDS buffer with one "is there" bit per
+//      byte, 64 consecutive tokens at a time, one per lane: literals and matches whose source
+//      lies below the super-round (memory; all lanes' loads in flight together) at once, a match
+//      into the buffer as soon as its source is there (LDS operations of a wave complete in
+//      order, so no fence is needed between lanes; the lowest waiting match always has its
+//      source, so the loop ends).  The buffer is then copied out with aligned 4-byte stores.
 // Anything irregular (code the tables cannot resolve at all, invalid symbol, -11, output
 // full, input exhausted, little input left) is not handled here: the super-round is cut
 // before it, or dropped, and decode_block -- the exact decoder -- takes over from a token
@@ -511,6 +513,7 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
 // 1: go on with decode_block at R.consumed.
 constexpr uint32_t kSegBits = 512;
 constexpr uint32_t kObuf = 8192;  // bytes of output assembled per super-round
+constexpr uint32_t kTokMax = 1024;  // tokens per super-round
 constexpr uint32_t kSegWords = kSegBits / 32;
 constexpr uint32_t kStageWords = kWave * kSegWords + 96;
 // staged word i lives at i + i / kSegWords: lanes read kSegWords apart, and an odd stride spreads
@@ -593,7 +596,7 @@ __device__ inline LaneTok lane_token(const DecTab &LT, const DecTab &DT, const u
 
 __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
                                 uint32_t *stage /* LDS, kStageWords */, uint32_t *bm /* LDS, kSegWords * 64 */, uint32_t *ob /* LDS, kObuf/4 + 2 */,
-                                uint32_t *wbm /* LDS, kObuf/32 */, uint32_t *dbg) {
+                                uint32_t *wbm /* LDS, kObuf/32 */, uint32_t *toks /* LDS, 2 * kTokMax */, uint32_t *dbg) {
   const uint32_t ext = (O.dict && !O.dict_loaded) ? O.dlen : 0u;  // LD:2367-2377
   const uint64_t nbits = (uint64_t)R.nbytes * 8;
   const uint64_t skip_bits = (uint64_t)R.skip * 8;
@@ -601,6 +604,7 @@ __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R
   for (;;) {
     R.consumed = bp;
     if (bp + 4 * kSegBits > nbits) return 1;  // the tail of a stream is not worth a super-round
+    uint64_t tk0 = wall_clock64();
     // ---- stage the input of the super-round; clear the bitmaps
     const uint64_t absbit = skip_bits + bp;
     const uint32_t w0i = (uint32_t)(absbit >> 5);
@@ -623,6 +627,7 @@ __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R
     __syncthreads();
     const int64_t left0 = (int64_t)(nbits - bp);  // stream bits from the super-round's start on
 
+    { uint64_t n = wall_clock64(); dbg[8] += (uint32_t)(n - tk0); tk0 = n; }
     // ---- A: own segment
     const uint32_t seg0 = lane * kSegBits, seg1 = seg0 + kSegBits;
     uint32_t pos = seg0;
@@ -638,6 +643,7 @@ __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R
       pos += t.bits;
     }
     __syncthreads();
+    { uint64_t n = wall_clock64(); dbg[9] += (uint32_t)(n - tk0); tk0 = n; }
     // ---- B: on into the next segment until a start of its lane is met
     // fin = where this lane's stretch ends if the lane is valid: the meeting point, or the token at
     // which it stopped (end of block: fin is that token; irregular / nothing met: a token boundary)
@@ -660,6 +666,7 @@ __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R
       }
       fin = pos;
     }
+    { uint64_t n = wall_clock64(); dbg[10] += (uint32_t)(n - tk0); tk0 = n; }
     // ---- valid lanes: 0 .. first lane that did not meet its neighbour
     const unsigned long long syncm = __ballot(synced);
     const uint32_t kt = (uint32_t)__builtin_ctzll(~syncm);  // (lane 63 never syncs: kt <= 63)
@@ -671,132 +678,145 @@ __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R
     if (t_fin == 0) return 1;  // nothing decodable at the very first token
     dbg[0]++; dbg[1] += kt + 1; dbg[2] += t_fin; dbg[3] += t_kind == 3; dbg[4] += t_kind == 2;
 
-    // ---- C: bytes each valid lane will write
-    uint32_t nb = 0;
+    // ---- C: bytes and tokens of each valid lane; where they go
+    uint32_t nb = 0, nt = 0;
     if (valid) {
       uint32_t p = st;
       while (p < fin) {
         const LaneTok t = lane_token(LT, DT, stage, stage_off, p, left0 - (int64_t)p);
         nb += t.kind == 0 ? 1u : t.a;
+        nt++;
         p += t.bits;
       }
     }
-    uint32_t incl = nb;
+    uint32_t incl = nb, tincl = nt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t u = __shfl_up(incl, off);
-      if (lane >= (uint32_t)off) incl += u;
+      const uint32_t u = __shfl_up(incl, off), v = __shfl_up(tincl, off);
+      if (lane >= (uint32_t)off) {
+        incl += u;
+        tincl += v;
+      }
     }
-    uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    if (total > kObuf) {  // keep the lanes whose output fits the assembly buffer
-      const uint32_t nfit = (uint32_t)__popcll(__ballot(valid && incl <= kObuf));
+    uint32_t total = __builtin_amdgcn_readlane(incl, 63), ntok = __builtin_amdgcn_readlane(tincl, 63);
+    if (total > kObuf || ntok > kTokMax) {  // keep the lanes whose output fits the buffers
+      const uint32_t nfit = (uint32_t)__popcll(__ballot(valid && incl <= kObuf && tincl <= kTokMax));
       if (nfit == 0) return 1;
       valid = lane < nfit;
       total = __builtin_amdgcn_readlane(incl, nfit - 1);
+      ntok = __builtin_amdgcn_readlane(tincl, nfit - 1);
       t_kind = 0;
       t_fin = __builtin_amdgcn_readlane(fin, nfit - 1);
     }
     if (O.opos + total > O.cap) return 1;  // the exact decoder finds the token that does not fit
 
-    // ---- D: assemble the super-round's output in LDS.  wbm has one bit per byte that is there.
+    { uint64_t n = wall_clock64(); dbg[11] += (uint32_t)(n - tk0); tk0 = n; }
+    // ---- C2: the token list, in stream order: {destination | length << 16 (0: literal), distance or byte}
+    if (valid) {
+      uint32_t p = st, dst = incl - nb, ti = tincl - nt;
+      while (p < fin) {
+        const LaneTok t = lane_token(LT, DT, stage, stage_off, p, left0 - (int64_t)p);
+        const uint32_t len = t.kind == 0 ? 0u : t.a;
+        toks[2 * ti] = dst | (len << 16);
+        toks[2 * ti + 1] = t.kind == 0 ? t.a : t.b;
+        dst += t.kind == 0 ? 1u : t.a;
+        ti++;
+        p += t.bits;
+      }
+    }
     for (uint32_t i = lane; i < kObuf / 32; i += kWave) wbm[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // what is below O.opos in memory is complete
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __syncthreads();
+
+    { uint64_t n = wall_clock64(); dbg[12] += (uint32_t)(n - tk0); tk0 = n; }
+    // ---- D: assemble the output in LDS, 64 consecutive tokens at a time (one per lane).  wbm has one
+    // bit per byte that is there.  Tokens of earlier groups are complete; inside a group a match waits
+    // until the part of its source that lies in the buffer is there (the lowest waiting one always is).
     uint8_t *ob8 = (uint8_t *)ob;
-    uint32_t orel = incl - nb;  // where this lane writes next, relative to O.opos
-    uint32_t p = st;
-    bool done = !valid || p >= fin;
     bool bad = false;
-    LaneTok t{0, 0, 0, 0};
-    bool have = false;  // t is the token at p (a waiting lane does not decode it again)
-    while (__ballot(!done)) {
-      dbg[5]++;
-      if (!done && !have) {
-        t = lane_token(LT, DT, stage, stage_off, p, left0 - (int64_t)p);
-        have = true;
-      }
-      if (!done && t.kind == 0) {
-        ob8[orel] = (uint8_t)t.a;
-        atomicOr(&wbm[orel >> 5], 1u << (orel & 31));
-        orel++;
-        p += t.bits;
-        have = false;
-        if (p >= fin) done = true;
-      } else if (!done) {
-        const uint32_t len = t.a, d = t.b;
-        if ((uint64_t)d > O.opos + orel + ext) {  // LD:2406-2410: the exact decoder reports it
+    for (uint32_t g0 = 0; g0 < ntok; g0 += kWave) {
+      const bool have = g0 + lane < ntok;
+      const uint32_t w0 = have ? toks[2 * (g0 + lane)] : 0u, w1 = have ? toks[2 * (g0 + lane) + 1] : 0u;
+      const uint32_t dst = w0 & 0xFFFF, len = w0 >> 16, d = w1;
+      bool pending = false;
+      int32_t a0 = 0, b0 = 0;
+      if (have && len == 0) {
+        ob8[dst] = (uint8_t)w1;
+        atomicOr(&wbm[dst >> 5], 1u << (dst & 31));
+      } else if (have) {
+        if ((uint64_t)d > O.opos + dst + ext) {  // LD:2406-2410: the exact decoder reports it
           bad = true;
-          done = true;
         } else {
           // source = bytes [a0, b0) relative to O.opos, repeated with period d if it runs into the
-          // destination; what lies below 0 is finished output in memory (or the dictionary), the
-          // rest must already be in the buffer
-          const int32_t a0 = (int32_t)orel - (int32_t)d;
-          const int32_t b0 = a0 + (int32_t)(len < d ? len : d);
-          bool ready = true;
-          if (b0 > 0) {
-            const uint32_t ra = a0 > 0 ? (uint32_t)a0 : 0u, rb = (uint32_t)b0;
-            for (uint32_t w = ra >> 5; w <= (rb - 1) >> 5; w++) {
-              const uint32_t lo = w * 32 < ra ? ra - w * 32 : 0u;
-              const uint32_t hi = rb < w * 32 + 32 ? rb - w * 32 : 32u;  // bits [lo, hi)
-              const uint32_t mask = (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-              if ((wbm[w] & mask) != mask) ready = false;
-            }
-          }
-          if (ready) {
-            if (b0 <= 0) {  // all of it from memory: 16 loads in flight, then 16 LDS stores
-              const int64_t s0 = (int64_t)O.opos + a0;
-              uint32_t j = 0;
-              for (uint32_t i0 = 0; i0 < len; i0 += 16) {
-                uint8_t tmp[16];
+          // destination; what lies below 0 is finished output in memory (or the dictionary)
+          a0 = (int32_t)dst - (int32_t)d;
+          b0 = a0 + (int32_t)(len < d ? len : d);
+          if (b0 <= 0) {  // all of it from memory: every lane's loads are in flight together
+            const int64_t s0 = (int64_t)O.opos + a0;
+            uint32_t j = 0;
+            for (uint32_t i0 = 0; i0 < len; i0 += 16) {
+              uint8_t tmp[16];
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) {
-                  const int64_t si = s0 + j;
-                  const uint8_t *sp = si < 0 ? O.dict + ((int64_t)O.dlen + si) : O.out + si;
-                  tmp[k] = i0 + k < len ? *sp : (uint8_t)0;
-                  j = j + 1 == d ? 0 : j + 1;  // (wraps only for a match at the very start of the buffer)
-                }
+              for (uint32_t k = 0; k < 16; k++) {
+                const int64_t si = s0 + j;
+                const uint8_t *sp = si < 0 ? O.dict + ((int64_t)O.dlen + si) : O.out + si;
+                tmp[k] = i0 + k < len ? *sp : (uint8_t)0;
+                j = j + 1 == d ? 0 : j + 1;  // (wraps only for a match at the very start of the buffer)
+              }
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++)
-                  if (i0 + k < len) ob8[orel + i0 + k] = tmp[k];
-              }
-            } else if (a0 >= 0) {  // all of it in the buffer
-              uint32_t j = 0;
-              for (uint32_t i = 0; i < len; i++) {
-                ob8[orel + i] = ob8[(uint32_t)a0 + j];
-                j = j + 1 == d ? 0 : j + 1;
-              }
-            } else {  // straddles the start of the super-round
-              uint32_t j = 0;
-              for (uint32_t i = 0; i < len; i++) {
-                const int32_t r = a0 + (int32_t)j;
-                uint8_t byte;
-                if (r >= 0) {
-                  byte = ob8[r];
-                } else {
-                  const int64_t si = (int64_t)O.opos + r;
-                  byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
-                }
-                ob8[orel + i] = byte;
-                j = j + 1 == d ? 0 : j + 1;
-              }
+              for (uint32_t k = 0; k < 16; k++)
+                if (i0 + k < len) ob8[dst + i0 + k] = tmp[k];
             }
-            for (uint32_t w = orel >> 5; w <= (orel + len - 1) >> 5; w++) {
-              const uint32_t lo = w * 32 < orel ? orel - w * 32 : 0u;
-              const uint32_t hi = orel + len < w * 32 + 32 ? orel + len - w * 32 : 32u;
+            for (uint32_t w = dst >> 5; w <= (dst + len - 1) >> 5; w++) {
+              const uint32_t lo = w * 32 < dst ? dst - w * 32 : 0u;
+              const uint32_t hi = dst + len < w * 32 + 32 ? dst + len - w * 32 : 32u;
               atomicOr(&wbm[w], (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u));
             }
-            orel += len;
-            p += t.bits;
-            have = false;
-            if (p >= fin) done = true;
+          } else {
+            pending = true;
           }
         }
       }
+      if (__ballot(bad)) return 1;  // nothing of this super-round has reached memory
+      while (__ballot(pending)) {
+        __syncthreads();
+        if (pending) {
+          const uint32_t ra = a0 > 0 ? (uint32_t)a0 : 0u, rb = (uint32_t)b0;
+          bool ready = true;
+          for (uint32_t w = ra >> 5; w <= (rb - 1) >> 5; w++) {
+            const uint32_t lo = w * 32 < ra ? ra - w * 32 : 0u;
+            const uint32_t hi = rb < w * 32 + 32 ? rb - w * 32 : 32u;  // bits [lo, hi)
+            const uint32_t mask = (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+            if ((wbm[w] & mask) != mask) ready = false;
+          }
+          if (ready) {
+            uint32_t j = 0;
+            for (uint32_t i = 0; i < len; i++) {
+              const int32_t r = a0 + (int32_t)j;
+              uint8_t byte;
+              if (r >= 0) {
+                byte = ob8[r];
+              } else {  // straddles the start of the super-round
+                const int64_t si = (int64_t)O.opos + r;
+                byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
+              }
+              ob8[dst + i] = byte;
+              j = j + 1 == d ? 0 : j + 1;
+            }
+            for (uint32_t w = dst >> 5; w <= (dst + len - 1) >> 5; w++) {
+              const uint32_t lo = w * 32 < dst ? dst - w * 32 : 0u;
+              const uint32_t hi = dst + len < w * 32 + 32 ? dst + len - w * 32 : 32u;
+              atomicOr(&wbm[w], (hi == 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u));
+            }
+            pending = false;
+          }
+        }
+      }
+      __syncthreads();
     }
-    if (__ballot(bad)) return 1;  // nothing of this super-round has reached memory
     __syncthreads();
+    { uint64_t n = wall_clock64(); dbg[13] += (uint32_t)(n - tk0); tk0 = n; }
     {  // buffer -> memory: bytes up to the first 4-byte boundary of the destination, dwords, bytes
       uint8_t *g = O.out + O.opos;
       uint32_t head = (uint32_t)((4 - ((uintptr_t)g & 3)) & 3);
@@ -811,6 +831,7 @@ __device__ int decode_block_seg(const DecTab &LT, const DecTab &DT, BitReader &R
       const uint32_t done_b = head + 4 * ndw;
       if (lane < total - done_b) g[done_b + lane] = ob8[done_b + lane];
     }
+    { uint64_t n = wall_clock64(); dbg[14] += (uint32_t)(n - tk0); tk0 = n; }
     O.opos += total;
     bp += t_fin;
     if (t_kind == 2) {  // the end-of-block code itself
@@ -836,6 +857,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
   __shared__ uint32_t s_bm[kSegWords * kWave];
   __shared__ uint32_t s_ob[kObuf / 4 + 2];
   __shared__ uint32_t s_wbm[kObuf / 32];
+  __shared__ uint32_t s_toks[2 * kTokMax];
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
   const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
@@ -850,7 +872,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
   O.dict_loaded = false;
 
   int status = 0;
-  uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t dbg[16] = {0};
   uint32_t expect = 0;
   int fixed_ready = 0;
   do {
@@ -898,7 +920,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
           fixed_ready = 1;
         }
         status = 0;
-        if ((A.tune & 8) || decode_block_seg(LT, DT, R, O, lane, s_stage, s_bm, s_ob, s_wbm, dbg) != 0)
+        if ((A.tune & 8) || decode_block_seg(LT, DT, R, O, lane, s_stage, s_bm, s_ob, s_wbm, s_toks, dbg) != 0)
           status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
       } else if (type == 2) {  // LD:2506-2615
         fixed_ready = 0;
@@ -958,7 +980,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
         err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
         status = 0;
-        if ((A.tune & 8) || decode_block_seg(LT, DT, R, O, lane, s_stage, s_bm, s_ob, s_wbm, dbg) != 0)
+        if ((A.tune & 8) || decode_block_seg(LT, DT, R, O, lane, s_stage, s_bm, s_ob, s_wbm, s_toks, dbg) != 0)
           status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
       } else {
         status = -1;
@@ -973,7 +995,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
   } while (false);
 
   if ((A.tune & 16) && s == 0 && lane == 0)
-    printf("seg: rounds %u lanes %u bits %u irregular %u eob %u Diters %u\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]);
+    printf("seg: rounds %u lanes %u bits %u irr %u eob %u | ticks stage %u A %u B %u C %u C2 %u D %u flush %u\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[8], dbg[9], dbg[10], dbg[11], dbg[12], dbg[13], dbg[14]);
   if (lane == 0) {
     const int64_t left = br_left(R);
     A.status[s] = status;
