@@ -44,7 +44,6 @@ struct InflateArgs {
   uint32_t *bytes_left;
   int32_t *status;
   uint32_t *expect_adler;  // zlib trailer value per stream (checked by k_zlib_check)
-  uint32_t tune;           // experiment switches (LDH_TUNE_INFLATE), 0 in production
 };
 
 struct BitReader {
@@ -297,7 +296,7 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // overlaps the next round's decode; matches that read recent output are copied in order.
 // Tokens the tables cannot resolve fall back to decode_one.
 __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
-                            uint32_t *s_in /* LDS, 64 dwords */, uint32_t tune) {
+                            uint32_t *s_in /* LDS, 64 dwords */) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
     ext = O.dlen;
@@ -549,7 +548,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
           build_table(DT, lens + 288, 32, 5, kLutBits, lane);
           fixed_ready = 1;
         }
-        status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
+        status = decode_block(LT, DT, R, O, lane, s_in);
       } else if (type == 2) {  // LD:2506-2615
         fixed_ready = 0;
         const uint32_t nlen = br_read(R, 5, lane) + 257;
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
         err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
-        status = decode_block(LT, DT, R, O, lane, s_in, A.tune);
+        status = decode_block(LT, DT, R, O, lane, s_in);
       } else {
         status = -1;
       }

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
   const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
   const uint8_t *lb8 = (const uint8_t *)lbytes;
-  const uint32_t refill_idle = B.tune[0] ? B.tune[0] : kRefillIdle;
+  const uint32_t refill_idle = kRefillIdle;
 
   // The scalar unit (exec-mask bookkeeping of divergent branches) bounds this loop, so the
   // chain step is written predicated; only the full compare is a divergent branch, the

@@ -234,12 +234,6 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.level = level;
     B.strategy = strategy;
     B.fmt = fmt;
-    for (int t = 0; t < 4; t++) {
-      char nm[16];
-      snprintf(nm, sizeof(nm), "LDH_TUNE%d", t);
-      const char *ev = getenv(nm);
-      B.tune[t] = ev ? (uint32_t)strtoul(ev, nullptr, 10) : 0;
-    }
     B.vbuf = (uint8_t *)g_vbuf.p;
     B.prevd = (uint16_t *)g_prevd.p;
     B.bufA = (uint32_t *)g_bufA.p;
@@ -323,7 +317,6 @@ int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, const u
   A.bytes_left = d_bytes_left;
   A.status = d_status;
   A.expect_adler = (uint32_t *)g_misc32a.p;
-  if (const char *ev = getenv("LDH_TUNE_INFLATE")) A.tune = (uint32_t)strtoul(ev, nullptr, 10);
   LAUNCH("k_inflate", k_inflate, (uint32_t)count, kWave, 0, A);
   if (fmt == 1) {
     LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)d_out,

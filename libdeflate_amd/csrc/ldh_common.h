@@ -128,7 +128,6 @@ struct Batch {
   uint32_t nvp;         // per-stream stride (elements) of the per-position arrays
   uint32_t max_blocks;  // num_blocks(max_len)
   int level, strategy, fmt;
-  uint32_t tune[4];     // experiment knobs (env LDH_TUNE0..3), 0 = built-in default
   // workspace
   uint8_t *vbuf;        // count * (nvp + kVPad)  virtual buffers
   uint16_t *prevd;      // count * nvp   distance to the previous same-trigram position (0 none)
