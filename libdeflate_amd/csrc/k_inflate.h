@@ -19,14 +19,22 @@ namespace ldh {
 constexpr int kLutBits = 10;
 constexpr int kLutSize = 1 << kLutBits;
 
-struct DecTab {
-  uint16_t lut[kLutSize];  // (sym << 4) | len for codes of <= lut_bits bits; 0 = slow path
-  uint16_t symbols[288];   // puff order: by (length, symbol)
+// LDS per wavefront decides how many of a batch's streams are resident at once (one stream = one
+// wavefront, 32 wavefronts per CU at most), so the tables are sized per use: literal/length codes get
+// a 10-bit lookup and 288 symbols, distance (and code-length) codes a 9-bit lookup and 32 symbols.
+template <int LUT_BITS, int NSYM>
+struct DecTabT {
+  static constexpr int kBits = LUT_BITS;
+  static constexpr int kSize = 1 << LUT_BITS;
+  uint16_t lut[kSize];     // (sym << 4) | len for codes of <= kBits bits; 0 = slow path
+  uint16_t symbols[NSYM];  // puff order: by (length, symbol)
   uint32_t counts[16];
   uint32_t offs[16];
   uint32_t first[16];      // first canonical code of each length
   uint32_t running[16];
 };
+using LitTab = DecTabT<kLutBits, 288>;
+using DistTab = DecTabT<9, 32>;
 
 struct InflateArgs {
   const uint8_t *in;
@@ -123,6 +131,7 @@ __device__ inline void br_align(BitReader &R, uint32_t lane) {  // SkipToByteBou
 // GetHuffmanForDecode (LD:2303-2344) over lens[0..nsym) (LDS).  Returns `left`:
 // 0 complete (also when there is no code at all, LD:2312-2314), > 0 incomplete,
 // < 0 over-subscribed.  Called by the whole wavefront (block = one wavefront).
+template <class DecTab>
 __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bitlen, int lut_bits,
                            uint32_t lane) {
   if (lane < 16) {
@@ -131,7 +140,7 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
     T.offs[lane] = 0;
     T.first[lane] = 0;
   }
-  for (int i = lane; i < kLutSize; i += kWave) T.lut[i] = 0;
+  for (int i = lane; i < DecTab::kSize; i += kWave) T.lut[i] = 0;
   __syncthreads();
   for (int base = 0; base < nsym; base += kWave) {
     const int i = base + (int)lane;
@@ -182,6 +191,7 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
 }
 
 // Decode (LD:2206-2256).  Returns the symbol or -10; consumes its bits.
+template <class DecTab>
 __device__ inline int decode_sym(const DecTab &T, int lut_bits, BitReader &R, uint32_t lane) {
   br_refill(R, lane);
   const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.lut[R.bitbuf & ((1u << lut_bits) - 1u)]);
@@ -230,7 +240,7 @@ struct OutState {
 // codes).  *eob is set when the token was the end-of-block symbol.
 // The reference's buffer_size only differs from the output position after it reached 65536,
 // where no distance (<= 32768) can fail, so `dist > opos + ext` is the -11 test (LD:2406-2410).
-__device__ int decode_one(const DecTab &LT, const DecTab &DT, int lbits, int dbits, BitReader &R,
+__device__ int decode_one(const LitTab &LT, const DistTab &DT, int lbits, int dbits, BitReader &R,
                           OutState &O, uint32_t ext, uint32_t lane, bool *eob) {
   const int symbol = decode_sym(LT, lbits, R, lane);
   *eob = symbol == 256;
@@ -295,7 +305,7 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // is loaded at once (one lane per byte) and stored a round later, so that the load latency
 // overlaps the next round's decode; matches that read recent output are copied in order.
 // Tokens the tables cannot resolve fall back to decode_one.
-__device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, OutState &O, uint32_t lane,
+__device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
                             uint32_t *s_in /* LDS, 64 dwords */) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
@@ -333,7 +343,7 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
     const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
     const uint64_t win = ((uint64_t)hi << 32) | lo;
-    const uint32_t e = LT.lut[lo & (kLutSize - 1)];
+    const uint32_t e = LT.lut[lo & (LitTab::kSize - 1)];
     const uint32_t sym = e >> 4, l1 = e & 15;
     const bool is_lit = sym < 256, is_eob = sym == 256, is_len = sym > 256;
     bool slow = e == 0;
@@ -344,7 +354,7 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
     const uint32_t mlen = lbase + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
     const uint32_t t = l1 + leb;
     const uint32_t din = (uint32_t)(win >> t);
-    const uint32_t e2 = DT.lut[din & (kLutSize - 1)];
+    const uint32_t e2 = DT.lut[din & (DistTab::kSize - 1)];
     const uint32_t dsym = e2 >> 4, l2 = e2 & 15;
     slow = slow | (is_len & (e2 == 0));
     bad = bad | (is_len & (dsym > 29));
@@ -465,7 +475,7 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
     if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
       br_seek_bits(R, bp, lane);
       bool eob = false;
-      const int st = decode_one(LT, DT, kLutBits, kLutBits, R, O, ext, lane, &eob);
+      const int st = decode_one(LT, DT, LitTab::kBits, DistTab::kBits, R, O, ext, lane, &eob);
       if (st != 0) return st;
       if (eob) return 0;
       bp = R.consumed;
@@ -484,8 +494,9 @@ __device__ int decode_block(const DecTab &LT, const DecTab &DT, BitReader &R, Ou
   }
 }
 
-__global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
-  __shared__ DecTab LT, DT;
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate(InflateArgs A) {
+  __shared__ LitTab LT;
+  __shared__ DistTab DT;
   __shared__ uint8_t lens[320 + 32];
   __shared__ uint32_t s_in[kWave + 4];
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
@@ -544,8 +555,8 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
           for (int i = lane; i < 288; i += kWave) lens[i] = (uint8_t)fixed_lit_bits(i);
           if (lane < 32) lens[288 + lane] = 5;
           __syncthreads();
-          build_table(LT, lens, 288, 9, kLutBits, lane);
-          build_table(DT, lens + 288, 32, 5, kLutBits, lane);
+          build_table(LT, lens, 288, 9, LitTab::kBits, lane);
+          build_table(DT, lens + 288, 32, 5, DistTab::kBits, lane);
           fixed_ready = 1;
         }
         status = decode_block(LT, DT, R, O, lane, s_in);
@@ -602,9 +613,9 @@ __global__ __launch_bounds__(kWave) void k_inflate(InflateArgs A) {
         __syncthreads();
         if (lane < 32) lens[320 + lane] = dl;
         __syncthreads();
-        int err = build_table(LT, lens, (int)nlen, 15, kLutBits, lane);
+        int err = build_table(LT, lens, (int)nlen, 15, LitTab::kBits, lane);
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
-        err = build_table(DT, lens + 320, (int)ndist, 15, kLutBits, lane);
+        err = build_table(DT, lens + 320, (int)ndist, 15, DistTab::kBits, lane);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
         status = decode_block(LT, DT, R, O, lane, s_in);
       } else {
