@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     }
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
-    const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~63u;  // positions whose links fit V's LDS
+    const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~1u;  // positions whose links fit V's LDS (>= 24, even)
     for (uint32_t h0 = 0; h0 < nv; h0 += H) {
       for (uint32_t r = tid; r < nv; r += kSortThreads) {
         const uint32_t v = SRT(r);

@@ -162,6 +162,40 @@ def test_large_streams(LD, B):
             assert g == o_compress(s, zlib=True, level=level, dict=dct), (level, len(s))
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 15, 16, 17, 47, 48, 63, 64, 65, 80, 127, 128, 129])
+def test_tiny_batches(B, n):
+    # a batch whose longest stream is tiny sizes every per-stream buffer (and every loop bound derived from it) small
+    for s in (b"x" * n, bytes(range(n))):
+        for level in (1, 5):
+            got = B.compress_batch([s], level=level)
+            assert got[0] == o_compress(s, level=level), (n, level)
+            assert B.decompress_batch([got[0][0]], max_out=max(n, 1))[0][0] == s
+
+
+def test_corpus_shapes(B):
+    # Synthetic stand-ins for the shapes of the reference's third-party corpus (tests/data/3rdparty, exercised by
+    # T:1067-1307): incompressible data (stored blocks win), binary records, long zero runs, tiny strings, a short
+    # phrase repeated, a string followed by its reverse.  (Those files themselves are not copied into this repo.)
+    rng = np.random.default_rng(17)
+    rec = np.zeros((6000, 20), dtype=np.uint8)
+    rec[:, 0] = 0x0A
+    rec[:, 1:5] = rng.integers(0, 4, (6000, 4))
+    rec[:, 5:9] = np.arange(6000, dtype=np.uint32).view(np.uint8).reshape(-1, 4)
+    rec[:, 9:] = rng.integers(0, 256, (6000, 11)) * (rng.integers(0, 8, (6000, 11)) == 0)
+    fox = b"The quick brown fox jumps over the lazy dog"
+    walk = bytes(rng.integers(0, 256, 33000, dtype=np.uint8))
+    cases = [b"", b"x", b"xyzzy", b"xxxxxxxxxxyyyyyyyyyy", b"x" * 64, fox, fox * 4096, bytes(rng.integers(0, 256, 123093, dtype=np.uint8)),
+             rec.tobytes(), b"\x00" * 262144, walk + walk[::-1], bytes(rng.integers(0, 256, 10000, dtype=np.uint8)),
+             bytes((rng.integers(0, 256, 50000) * (rng.integers(0, 3, 50000) == 0)).astype(np.uint8))]
+    for level, strategy in ((0, None), (1, None), (3, None), (5, None), (8, None), (5, "fixed"), (5, "dynamic"),
+                            (1, "huffman_only"), (None, None)):
+        got = B.compress_batch(cases, level=level, strategy=strategy)
+        for s, g in zip(cases, got):
+            assert g == o_compress(s, level=level, strategy=strategy), (level, strategy, len(s))
+        back = B.decompress_batch([c for c, _ in got], max_out=262144)
+        assert [x for x, _ in back] == cases
+
+
 def test_no_dependence_on_stale_buffers(B):
     cases = _small() + _files()
     os.environ["LDH_POISON"] = "1"
