@@ -172,6 +172,41 @@ def test_tiny_batches(B, n):
             assert B.decompress_batch([got[0][0]], max_out=max(n, 1))[0][0] == s
 
 
+def test_random_batch_shapes(LD, B):
+    # many small batches of random composition: sizes, content classes, level, format, dictionary -- every buffer size
+    # and loop bound that is derived from the batch (not from the stream) gets exercised at odd values
+    rng = np.random.default_rng(2024)
+    dct = golden("dictionary32768.txt")
+    dicts = {n: LD.CreateDictionary(dct[-n:], n, o_adler32(dct[-n:])) for n in (5, 300, 32768)}
+    text = golden("totalrp3.txt")
+
+    def stream():
+        kind = int(rng.integers(0, 5))
+        n = int(rng.choice([0, 1, 2, 3, 7, 31, 32, 33, 95, 96, 97, 200, 1000, 4096, 5000, 66000], p=[.05] * 8 + [.08] * 4 + [.1, .1, .04, .04]))
+        if kind == 0:
+            return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        if kind == 1:
+            return bytes(rng.integers(97, 100, n, dtype=np.uint8))
+        if kind == 2:
+            o = int(rng.integers(0, len(text) - n - 1))
+            return text[o:o + n]
+        if kind == 3:
+            return (b"ab" * n)[:n]
+        return dct[-n:] if n else b""
+
+    for it in range(120):
+        cases = [stream() for _ in range(int(rng.integers(1, 5)))]
+        level = [None, 0, 1, 2, 3, 4, 5, 6, 7][int(rng.integers(0, 9))]
+        fmt = int(rng.integers(0, 2))
+        dn = [None, 5, 300, 32768][int(rng.integers(0, 4))]
+        d = dicts[dn] if dn else None
+        got = B.compress_batch(cases, fmt=fmt, level=level, dictionary=d)
+        for s, g in zip(cases, got):
+            assert g == o_compress(s, zlib=bool(fmt), level=level, dict=dct[-dn:] if dn else None), (it, level, fmt, dn, len(s))
+        back = B.decompress_batch([c for c, _ in got], fmt=fmt, dictionary=d, max_out=max(1, max(len(c) for c in cases)))
+        assert [x for x, _ in back] == cases, (it, level, fmt, dn)
+
+
 def test_corpus_shapes(B):
     # Synthetic stand-ins for the shapes of the reference's third-party corpus (tests/data/3rdparty, exercised by
     # T:1067-1307): incompressible data (stored blocks win), binary records, long zero runs, tiny strings, a short
