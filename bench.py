@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=8192, help="streams per GPU (each 131072 B)")
+    ap.add_argument("--stream-bytes", type=int, default=STREAM_LEN, help="bytes per stream (default 131072; 4096 = configs[1] shape)")
     ap.add_argument("--level", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-levels", action="store_true", help="skip the one-step runs at levels 1 and 8")
@@ -121,7 +122,7 @@ def main():
     from libdeflate_amd import batch as B
     N.init(local_rank)
 
-    S, L = args.streams, STREAM_LEN
+    S, L = args.streams, args.stream_bytes
     data = gen_text_device(torch, S, L, dev, SEED ^ rank)
     off = torch.arange(S + 1, dtype=torch.int64, device=dev) * L
     bt = B.DeviceBatch(data, off, L)
@@ -211,7 +212,7 @@ def main():
         except (OSError, KeyError, ValueError):
             traffic = None
         line = {
-            "metric": "input GB/s compress+decompress, level %d, batched 128 KB strings" % args.level,
+            "metric": "input GB/s compress+decompress, level %d, batched %d KB strings" % (args.level, L // 1024),
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",

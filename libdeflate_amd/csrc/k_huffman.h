@@ -40,59 +40,63 @@ __global__ __launch_bounds__(256) void k_histogram(Batch B) {
 // ------------------------------------------------------------------ k_huffman
 struct HuffScratch {
   uint32_t w[576];  // weight, later depth (LD:978)
-  int16_t sym[576], left[576], right[576];
-  int16_t leafs[288], heap[292], fifo[576];
+  int16_t sym[576];
+  int16_t leafs[288];
+  uint32_t hp[292];  // heap slots: weight << 10 | node
   uint32_t cnt[288];  // counts of the alphabet being built
   uint8_t len[288];
   uint16_t code[288];
   int bl_count[17];
+  int next_code[17];
+  int16_t parent[576];
+  int nnodes;
 };
 
+// The binary heap of LD:842-903 with its exact comparisons (children: the right one only if strictly
+// lighter; moves only while strictly lighter / heavier), so that ties fall as in the reference (Q7).
+// A heap slot holds weight << 10 | node, so a comparison costs one LDS read instead of two dependent
+// ones, and the sifted element is written once, where it ends up, instead of at every level (same
+// final array).  Weights are < 2^22 (a block has at most 65536 symbols).
 // LD:863-903
-__device__ inline int hs_pop(HuffScratch &S, int heap_size) {
-  const int top = S.heap[1];
-  const int e = S.heap[heap_size];
-  const uint32_t value = S.w[e];
-  S.heap[1] = (int16_t)e;
-  S.heap[heap_size] = (int16_t)top;
+__device__ inline uint32_t hs_pop(HuffScratch &S, int heap_size) {
+  const uint32_t top = S.hp[1];
+  const uint32_t e = S.hp[heap_size];
+  const uint32_t value = e >> 10;
   heap_size--;
-  int pos = 1, l = 2, r = 3;
+  int pos = 1, l = 2;
   while (l <= heap_size) {
-    const int lc = S.heap[l];
-    if (r <= heap_size && S.w[S.heap[r]] < S.w[lc]) {
-      const int rc = S.heap[r];
-      if (S.w[rc] < value) {
-        S.heap[r] = (int16_t)e;
-        S.heap[pos] = (int16_t)rc;
-        pos = r;
-      } else
-        break;
-    } else {
-      if (S.w[lc] < value) {
-        S.heap[l] = (int16_t)e;
-        S.heap[pos] = (int16_t)lc;
-        pos = l;
-      } else
-        break;
+    uint32_t c = S.hp[l];
+    int cp = l;
+    if (l + 1 <= heap_size) {
+      const uint32_t rc = S.hp[l + 1];
+      if ((rc >> 10) < (c >> 10)) {
+        c = rc;
+        cp = l + 1;
+      }
     }
-    l = pos * 2;
-    r = l + 1;
+    if ((c >> 10) < value) {
+      S.hp[pos] = c;
+      pos = cp;
+      l = pos * 2;
+    } else {
+      break;
+    }
   }
+  S.hp[pos] = e;
   return top;
 }
 // LD:842-856
-__device__ inline void hs_push(HuffScratch &S, int e, int heap_size) {
-  heap_size++;
-  S.heap[heap_size] = (int16_t)e;
-  const uint32_t value = S.w[e];
-  int pos = heap_size, parent = pos / 2;
-  while (parent >= 1 && S.w[S.heap[parent]] > value) {
-    const int t = S.heap[parent];
-    S.heap[parent] = (int16_t)e;
-    S.heap[pos] = (int16_t)t;
+__device__ inline void hs_push(HuffScratch &S, uint32_t e, int heap_size) {
+  const uint32_t value = e >> 10;
+  int pos = heap_size + 1, parent = pos / 2;
+  while (parent >= 1) {
+    const uint32_t pe = S.hp[parent];
+    if ((pe >> 10) <= value) break;
+    S.hp[pos] = pe;
     pos = parent;
     parent /= 2;
   }
+  S.hp[pos] = e;
 }
 
 // GetHuffmanBitlenAndCode (LD:968-1085) over S.cnt[0..nsym); results in S.len / S.code.
@@ -131,84 +135,105 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
         const int sy = S.leafs[i];
         S.w[i] = S.cnt[sy];
         S.sym[i] = (int16_t)sy;
-        S.left[i] = S.right[i] = -1;
-        S.heap[i + 1] = (int16_t)i;
+        S.hp[i + 1] = (S.cnt[sy] << 10) | (uint32_t)i;
       }
       int heap_size = nleaf, nnodes = nleaf;
       while (heap_size > 1) {  // LD:1006-1015
-        const int l = hs_pop(S, heap_size);
+        const uint32_t l = hs_pop(S, heap_size);
         heap_size--;
-        const int r = hs_pop(S, heap_size);
+        const uint32_t r = hs_pop(S, heap_size);
         heap_size--;
-        S.w[nnodes] = S.w[l] + S.w[r];
         S.sym[nnodes] = -1;
-        S.left[nnodes] = (int16_t)l;
-        S.right[nnodes] = (int16_t)r;
-        hs_push(S, nnodes, heap_size);
+        S.parent[l & 1023] = (int16_t)nnodes;
+        S.parent[r & 1023] = (int16_t)nnodes;
+        hs_push(S, (((l >> 10) + (r >> 10)) << 10) | (uint32_t)nnodes, heap_size);
         nnodes++;
         heap_size++;
       }
-      for (int i = 0; i <= 16; i++) S.bl_count[i] = 0;
-      int fifo_size = 1, index = 0, overflow = 0;
-      S.fifo[0] = S.heap[1];
-      S.w[S.heap[1]] = 0;
-      while (index < fifo_size) {  // LD:1025-1053
-        const int e = S.fifo[index];
-        int bitlen = (int)S.w[e];
-        if (S.left[e] >= 0) {
-          S.fifo[fifo_size++] = S.left[e];
-          S.w[S.left[e]] = bitlen + 1;
-        }
-        if (S.right[e] >= 0) {
-          S.fifo[fifo_size++] = S.right[e];
-          S.w[S.right[e]] = bitlen + 1;
-        }
-        index++;
-        if (bitlen > max_bitlen) {
-          overflow++;
-          bitlen = max_bitlen;
-        }
-        if (S.sym[e] >= 0) {
-          S.len[S.sym[e]] = (uint8_t)bitlen;
-          if (S.sym[e] > max_nz) max_nz = S.sym[e];
-          S.bl_count[bitlen]++;
+      S.parent[S.hp[1] & 1023] = -1;
+      S.nnodes = nnodes;
+    }
+  }
+  __syncthreads();
+  if (nleaf >= 2) {
+    // Depths (LD:1021-1053).  The reference walks the tree breadth first, but what it computes does
+    // not depend on the order: a node's depth, `overflow` = number of nodes (internal ones too) deeper
+    // than max_bitlen, leaf lengths clamped to max_bitlen, their histogram.  Every lane climbs from
+    // its nodes to the root.
+    const int nnodes = S.nnodes;
+    if (lane <= 16) S.bl_count[lane] = 0;
+    __syncthreads();
+    int over = 0;
+    for (int i = lane; i < nnodes; i += kWave) {
+      int depth = 0;
+      for (int p = S.parent[i]; p >= 0; p = S.parent[p]) depth++;
+      if (depth > max_bitlen) {
+        over++;
+        depth = max_bitlen;
+      }
+      const int sy = S.sym[i];
+      if (sy >= 0) {
+        S.len[sy] = (uint8_t)depth;
+        atomicAdd(&S.bl_count[depth], 1);
+        if (sy > max_nz) max_nz = sy;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      over += __shfl_xor(over, o);
+      const int m = __shfl_xor(max_nz, o);
+      max_nz = m > max_nz ? m : max_nz;
+    }
+    __syncthreads();
+    if (over > 0 && lane == 0) {  // LD:1057-1079
+      int overflow = over, bitlen, index = 0;
+      do {
+        bitlen = max_bitlen - 1;
+        while (bitlen > 0 && S.bl_count[bitlen] == 0) bitlen--;
+        if (bitlen <= 0) break;
+        S.bl_count[bitlen]--;
+        S.bl_count[bitlen + 1] += 2;
+        S.bl_count[max_bitlen]--;
+        overflow -= 2;
+      } while (overflow > 0);
+      for (bitlen = max_bitlen; bitlen >= 1; bitlen--) {
+        int k = S.bl_count[bitlen];
+        while (k > 0) {
+          S.len[S.leafs[index]] = (uint8_t)bitlen;
+          k--;
+          index++;
         }
       }
-      if (overflow > 0) {  // LD:1057-1079
-        int bitlen;
-        do {
-          bitlen = max_bitlen - 1;
-          while (bitlen > 0 && S.bl_count[bitlen] == 0) bitlen--;
-          if (bitlen <= 0) break;
-          S.bl_count[bitlen]--;
-          S.bl_count[bitlen + 1] += 2;
-          S.bl_count[max_bitlen]--;
-          overflow -= 2;
-        } while (overflow > 0);
-        index = 0;
-        for (bitlen = max_bitlen; bitlen >= 1; bitlen--) {
-          int k = S.bl_count[bitlen];
-          while (k > 0) {
-            S.len[S.leafs[index]] = (uint8_t)bitlen;
-            k--;
-            index++;
-          }
-        }
-      }
-      // LD:913-948 canonical codes, bit-reversed
-      int next_code[17];
+    }
+    __syncthreads();
+    // LD:913-948 canonical codes, bit-reversed: first code of each length, then symbols of one
+    // length in increasing order (rank among the wave's lanes by ballots, running count per length)
+    if (lane == 0) {
       int code = 0;
+      S.next_code[0] = 0;
       for (int bl = 1; bl <= max_bitlen; bl++) {
         code = (code + S.bl_count[bl - 1]) * 2;
-        next_code[bl] = code;
+        S.next_code[bl] = code;
       }
-      for (int sy = 0; sy < nsym; sy++) {
-        const int len = S.len[sy];
-        if (len) {
-          const uint32_t c = (uint32_t)next_code[len]++;
-          S.code[sy] = (uint16_t)(__brev(c) >> (32 - len));
-        }
+    }
+    __syncthreads();
+    for (int base = 0; base < nsym; base += kWave) {
+      const int sy = base + (int)lane;
+      const uint32_t len = sy < nsym ? S.len[sy] : 0;
+      const bool active = len != 0;
+      unsigned long long mask = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 4; bit++) {
+        const unsigned long long bal = __ballot(active && ((len >> bit) & 1));
+        mask &= ((len >> bit) & 1) ? bal : ~bal;
       }
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (active) {
+        const uint32_t c = (uint32_t)S.next_code[len] + rank;
+        S.code[sy] = (uint16_t)(__brev(c) >> (32 - len));
+      }
+      __syncthreads();
+      if (active && rank == 0) S.next_code[len] += (int)__popcll(mask);
+      __syncthreads();
     }
   }
   __syncthreads();
