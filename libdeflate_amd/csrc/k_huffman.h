@@ -39,7 +39,6 @@ __global__ __launch_bounds__(256) void k_histogram(Batch B) {
 
 // ------------------------------------------------------------------ k_huffman
 struct HuffScratch {
-  uint32_t w[576];  // weight, later depth (LD:978)
   int16_t sym[576];
   int16_t leafs[288];
   uint32_t hp[292];  // heap slots: weight << 10 | node
@@ -133,7 +132,6 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
     } else if (nleaf >= 2) {
       for (int i = 0; i < nleaf; i++) {
         const int sy = S.leafs[i];
-        S.w[i] = S.cnt[sy];
         S.sym[i] = (int16_t)sy;
         S.hp[i + 1] = (S.cnt[sy] << 10) | (uint32_t)i;
       }
