@@ -187,13 +187,18 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     __syncthreads();
   }
 
+  if (B.want_rank) {
+    // greedy levels walk the sorted array itself (k_lz_greedy): no links, only the inverse permutation
+    for (uint32_t r = tid; r < nv; r += kSortThreads) rank[SRT(r)] = r;
+    return;
+  }
   // links: neighbours in sorted order that share the trigram
   if (V_LDS) {
     // Scattering 2-byte links by position straight to memory cost as much as the whole sort.
     // Instead: (a) link values in sorted order, coalesced, into the free ping-pong buffer;
     // (b) V is no longer needed, so its LDS holds the links of 65536 positions at a time:
     // scatter there, then copy out in order.
-    uint16_t *dl = (uint16_t *)(B.want_rank ? bufA : bufB);
+    uint16_t *dl = (uint16_t *)bufB;
     for (uint32_t r = tid; r < nv; r += kSortThreads) {
       uint32_t dlt = 0;
       if (r > 0) {
@@ -203,7 +208,6 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
         if (tu == tv && v - u <= kWindow) dlt = v - u;
       }
       dl[r] = (uint16_t)dlt;
-      if (B.want_rank) rank[SRT(r)] = r;
     }
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
@@ -234,7 +238,6 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
         }
       }
       prevd[v] = (uint16_t)dlt;
-      if (B.want_rank) rank[v] = r;
     }
   }
 #undef VBYTE
