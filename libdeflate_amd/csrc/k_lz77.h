@@ -29,6 +29,23 @@ __device__ inline uint32_t trigram(const uint8_t *V, uint32_t v) {
   return ((uint32_t)V[v] << 16) | ((uint32_t)V[v + 1] << 8) | (uint32_t)V[v + 2];
 }
 
+// LDS reads at any byte offset.  gfx950 accepts misaligned ds_read_u16 / _b32 / _b64 (the
+// compiler emits them for align-1 loads), but they are slow: with one misaligned ds_read_u16
+// per chain step k_match_lazy took 91 ms instead of 33.  So: aligned reads + alignbyte.
+__device__ inline uint32_t lds_load2(const uint32_t *w, uint32_t byteoff) {
+  const uint8_t *b = (const uint8_t *)w + byteoff;
+  return (uint32_t)b[0] | ((uint32_t)b[1] << 8);
+}
+__device__ inline uint32_t lds_load4(const uint32_t *w, uint32_t byteoff) {
+  uint32_t i = byteoff >> 2;
+  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
+}
+__device__ inline uint64_t lds_load8(const uint32_t *w, uint32_t byteoff) {
+  const uint32_t i = byteoff >> 2, sh = byteoff & 3;
+  const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+  return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
+}
+
 // ------------------------------------------------------------------ k_sort_links
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
@@ -175,7 +192,8 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
         if (e[j] != 0xFFFFFFFFu) {
           const uint32_t at = s_bprev[d[j]] + s_pre[wave][d[j]] + lrank[j];
           if (pass == 2 && B.want_rank) {
-            const uint32_t w4 = VBYTE(e[j]) | (VBYTE(e[j] + 1) << 8) | (VBYTE(e[j] + 2) << 16) | (VBYTE(e[j] + 3) << 24);
+            const uint32_t w4 = V_LDS ? lds_load4((const uint32_t *)ldsV, e[j])
+                                      : VBYTE(e[j]) | (VBYTE(e[j] + 1) << 8) | (VBYTE(e[j] + 2) << 16) | (VBYTE(e[j] + 3) << 24);
             srt2[at] = make_uint2(e[j], w4);
           } else {
             dst[at] = e[j];
@@ -203,8 +221,8 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
       uint32_t dlt = 0;
       if (r > 0) {
         const uint32_t v = SRT(r), u = SRT(r - 1);
-        const uint32_t tu = (VBYTE(u) << 16) | (VBYTE(u + 1) << 8) | VBYTE(u + 2);
-        const uint32_t tv = (VBYTE(v) << 16) | (VBYTE(v + 1) << 8) | VBYTE(v + 2);
+        const uint32_t tu = lds_load4((const uint32_t *)ldsV, u) << 8;  // three bytes (V is zero padded)
+        const uint32_t tv = lds_load4((const uint32_t *)ldsV, v) << 8;
         if (tu == tv && v - u <= kWindow) dlt = v - u;
       }
       dl[r] = (uint16_t)dlt;
@@ -250,17 +268,8 @@ constexpr int kMatchThreads = 1024;
 constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
 constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
 constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
+constexpr uint32_t kMatchSteps = 8;   // chain steps between two looks at the long paths
 constexpr uint32_t kRefillIdle = 16;  // lanes that must be idle before the wave fetches new positions
-
-__device__ inline uint32_t lds_load4(const uint32_t *w, uint32_t byteoff) {
-  uint32_t i = byteoff >> 2;
-  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
-}
-__device__ inline uint64_t lds_load8(const uint32_t *w, uint32_t byteoff) {
-  const uint32_t i = byteoff >> 2, sh = byteoff & 3;
-  const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
-  return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
-}
 
 // One lane works on one position at a time and walks its chain one candidate per loop
 // trip; lanes whose chain has ended take the next position of the tile from a workgroup
@@ -293,10 +302,17 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     const uint32_t *gsrc = (const uint32_t *)(V + wbase);
     for (uint32_t i = tid; i < nb; i += kMatchThreads)
       lbytes[i] = (wbase + 4 * i + 4 <= alloc_end) ? gsrc[i] : 0u;
+    // "no link" (0) becomes 0xFFFF: a hop of 65535 always fails the window test, so the chain
+    // step needs no separate end-of-chain compare
     const uint32_t np = (v1 - wbase + 1) / 2;
     const uint32_t *psrc = (const uint32_t *)(prevd + wbase);
     uint32_t *pdst = (uint32_t *)lprev;
-    for (uint32_t i = tid; i < np; i += kMatchThreads) pdst[i] = psrc[i];
+    for (uint32_t i = tid; i < np; i += kMatchThreads) {
+      uint32_t x = psrc[i];
+      x |= (x & 0xFFFFu) ? 0u : 0xFFFFu;
+      x |= (x >> 16) ? 0u : 0xFFFF0000u;
+      pdst[i] = x;
+    }
     if (tid == 0) s_next = q0;
   }
   __syncthreads();
@@ -304,45 +320,53 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   // a tile (8192 positions) straddles at most one deflate-block end
   const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
   const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
-  const uint8_t *lb8 = (const uint8_t *)lbytes;
   const uint32_t refill_idle = kRefillIdle;
 
-  // The scalar unit (exec-mask bookkeeping of divergent branches) bounds this loop, so the
-  // chain step is written predicated; only the full compare is a divergent branch, the
-  // refill check runs once per kStepsPerCheck steps and results are stored at refill time.
-  // Lane states: idle (waits for the next refill), walking (`active`), or holding a candidate
-  // that passed the 2-byte quick reject and waits for the batched full compare (`cmpp`).
-  // The VALU is the bound (4 cycles per wave64 op), so the rare long paths -- refill and
-  // full compare -- run once per round for all lanes that need them instead of per step.
-  constexpr uint32_t steps_per_round = 8;
-  bool active = false, cmpp = false, pending = false, exhausted = false, seen_seed = false;
-  bool open = true;  // best < nice_length and best < maxlen: the walk may go on (LD:1389)
-  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, t2 = 0, dsave = 0;
-  uint32_t depth = 0;
+  // Instruction issue bounds this loop (a wave64 VALU op holds its SIMD for 4 cycles, the
+  // CU's one scalar unit issues one instruction per cycle), so the chain step is written to
+  // be as few instructions as possible.  Lane predicates live in wave-uniform 64-bit masks
+  // (a v_cmp writes one directly; combining two costs one scalar op), and the step has no
+  // per-lane "am I running" select: a lane whose candidate passed the quick reject does not
+  // advance, so every later step of the round re-evaluates the same candidate with the same
+  // outcome, and a lane whose chain has ended is simply not in `act`.  The long paths --
+  // full compare and refill -- run once per round for all lanes that need them.
+  //   act    lanes walking a chain (implies best < nice_length and best < maxlen, LD:1389)
+  //   pm     lanes whose current candidate passed the quick reject in the last step
+  //   pend   lanes holding a position whose result is not stored yet
+  //   seed   (dictionary) lanes whose walk has taken a candidate in the last two dictionary
+  //          bytes, after which LD:1394 lets it go no deeper into the dictionary
+  constexpr uint32_t steps_per_round = kMatchSteps;
+  unsigned long long act = 0, pm = 0, pend = 0, seed = 0;
+  bool exhausted = false;
+  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, t2 = 0, dn = 0xFFFFu;
+  uint32_t d1 = 0;   // candidates the walk may still evaluate after the current one (LD:1362)
+  uint32_t off = 0;  // best ? best - 1 : 0
+  int32_t lo = 0;    // vb - 32768: the farthest candidate inside the window (LD:1365)
   uint64_t tw = 0;
+  const uint64_t lane_bit = 1ull << lane;
 
-  // next hop after candidate `cb` was evaluated: LD:1389 nice_length, LD:1362 depth, chain
-  // end, LD:1365 window; a match of maxlen cannot be beaten (the walk has no side effects, so
-  // ending it early leaves the result unchanged)
-#define LDH_ADVANCE(cond, dn_)                                                                   \
-  {                                                                                              \
-    depth -= (cond) ? 1u : 0u;                                                                   \
-    const uint32_t cn_ = cb - (dn_);                                                             \
-    bool go_ = (cond) & open & (depth != 0) & ((dn_) != 0) & (vb - cn_ <= kWindow);             \
-    if (HAS_DICT) { /* dictionary side of V (Q10) */                                             \
-      const uint32_t c_ = cn_ + wbase;                                                           \
-      const bool in_dict_ = c_ < D, deep_ = c_ + 2 < D;                                          \
-      go_ = go_ & !(in_dict_ & deep_ & seen_seed); /* LD:1394: no fall-through after a seed */   \
-      seen_seed = seen_seed | (go_ & in_dict_ & !deep_);                                         \
-    }                                                                                            \
-    cb = go_ ? cn_ : cb;                                                                         \
-    active = (cond) ? go_ : active;                                                              \
+  // hop from candidate cb over link dn_ for the lanes in cond_; returns the lanes that go on
+#define LDH_HOP(cond_, dn_, go_)                                                                  \
+  {                                                                                               \
+    const unsigned long long more_ = __ballot(d1 != 0);                                           \
+    d1 -= (uint32_t)__builtin_amdgcn_inverse_ballot_w64(cond_);                                   \
+    const uint32_t cn_ = cb - (dn_);                                                              \
+    go_ = (cond_) & more_ & __ballot((int32_t)cn_ >= lo);                                         \
+    if (HAS_DICT) { /* dictionary side of V (Q10) */                                              \
+      const uint32_t c_ = cn_ + wbase;                                                            \
+      const unsigned long long in_dict_ = __ballot(c_ < D), deep_ = __ballot(c_ + 2 < D);         \
+      go_ &= ~(in_dict_ & deep_ & seed);                                                          \
+      seed |= go_ & in_dict_ & ~deep_;                                                            \
+    }                                                                                             \
+    cb = __builtin_amdgcn_inverse_ballot_w64(go_) ? cn_ : cb;                                     \
   }
 
   for (;;) {
     // ---- batched full compare of the candidates that passed the quick reject
-    if (__ballot(cmpp)) {
-      if (cmpp) {
+    const unsigned long long cm = act & pm;
+    pm = 0;
+    if (cm) {
+      if (cm & lane_bit) {
         const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
         uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
         if (x == 0) {
@@ -359,72 +383,74 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
         if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
           best = L;
           bdist = vb - cb;
-          t2 = (uint32_t)lb8[vb + best - 1] | ((uint32_t)lb8[vb + best] << 8);
-          open = (best < nice) & (best < maxlen);
+          off = best - 1;
+          t2 = lds_load2(lbytes, vb + off);
         }
-        LDH_ADVANCE(true, dsave);
-        cmpp = false;
       }
+      // a match of maxlen cannot be beaten (the walk has no side effects, so ending it early
+      // leaves the result unchanged)
+      const unsigned long long open = __ballot((best < nice) & (best < maxlen));
+      unsigned long long go;
+      LDH_HOP(cm & open, dn, go);
+      act = (act & ~cm) | go;
     }
     // ---- refill idle lanes
-    const unsigned long long idle = __ballot(!active);
+    const unsigned long long idle = ~act;
     const uint32_t nidle = (uint32_t)__popcll(idle);
     if (!exhausted && (nidle >= refill_idle)) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&s_next, nidle);
       base = __builtin_amdgcn_readfirstlane(base);
-      if (!active) {
-        if (pending) {
-          mout[q] = best ? ((best << 16) | bdist) : 0u;
-          pending = false;
-        }
-        const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+      bool started = false, has_pos = false;
+      if (idle & lane_bit) {
+        if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
+        const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
         if (my < q1) {
           const uint32_t p = my + 1;
           const uint32_t be = p <= be_lo ? be_lo : be_hi;
           if (p + 2 <= be) {  // LD:1349
             q = my;
             vb = my + D - wbase;
+            lo = (int32_t)vb - (int32_t)kWindow;
             const uint32_t d0 = lprev[vb];
             cb = vb - d0;
             maxlen = be - p + 1;
             if (maxlen > kMaxMatch) maxlen = kMaxMatch;
             tw = lds_load8(lbytes, vb + 3);
-            t2 = (uint32_t)lb8[vb] | ((uint32_t)lb8[vb + 1] << 8);
-            depth = (uint32_t)cfg.max_chain;  // Q3
+            t2 = lds_load2(lbytes, vb);
+            d1 = (uint32_t)cfg.max_chain - 1;  // Q3
             best = 0;
             bdist = 0;
-            open = true;
-            active = (d0 != 0) & (d0 <= kWindow);  // chain empty / LD:1365
-            seen_seed = HAS_DICT && active && (cb + wbase < D) && !(cb + wbase + 2 < D);
-            pending = true;
+            off = 0;
+            started = d0 <= kWindow;  // chain empty (0xFFFF) / LD:1365
+            has_pos = true;
           } else {
             mout[my] = 0;
           }
         }
       }
+      const unsigned long long st = __ballot(started);
+      act |= st;
+      pend = (pend & ~idle) | __ballot(has_pos);
+      if (HAS_DICT) seed = (seed & ~idle) | (st & __ballot((cb + wbase < D) & !(cb + wbase + 2 < D)));
       if (base + nidle >= q1) exhausted = true;
       continue;
     }
     if (nidle == 64) break;
-    // ---- chain steps: one LDS round trip each (link of the candidate + its reject bytes)
+    // ---- chain steps: one LDS round trip each (link of the candidate + its reject bytes).
+    // A candidate can only beat `best` if it also matches at offsets best-1 and best (the
+    // trigram makes offsets 0..2 equal): two bytes reject nearly every candidate.
 #pragma unroll
     for (uint32_t step = 0; step < steps_per_round; step++) {
-      const bool run = active & !cmpp;
-      const uint32_t cs = run ? cb : vb;
-      const uint32_t dn = lprev[cs];
-      // A candidate can only beat `best` if it also matches at offsets best-1 and best (the
-      // trigram makes offsets 0..2 equal): two byte reads reject nearly every candidate.
-      const uint32_t o = cs + (best ? best - 1 : 0);
-      const uint32_t q2 = (uint32_t)lb8[o] | ((uint32_t)lb8[o + 1] << 8);
-      const bool pass = run & (q2 == t2);
-      cmpp = cmpp | pass;
-      dsave = pass ? dn : dsave;
-      LDH_ADVANCE(run & !pass, dn);
+      dn = lprev[cb];
+      pm = __ballot(lds_load2(lbytes, cb + off) == t2);
+      unsigned long long go;
+      LDH_HOP(act & ~pm, dn, go);
+      act = (act & pm) | go;
     }
   }
-#undef LDH_ADVANCE
-  if (pending) mout[q] = best ? ((best << 16) | bdist) : 0u;
+#undef LDH_HOP
+  if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
 }
 
 // ------------------------------------------------------------------ k_parse_lazy
