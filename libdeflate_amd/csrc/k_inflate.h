@@ -305,6 +305,11 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // is loaded at once (one lane per byte) and stored a round later, so that the load latency
 // overlaps the next round's decode; matches that read recent output are copied in order.
 // Tokens the tables cannot resolve fall back to decode_one.
+// The scalar unit bounds this function (one instruction per cycle for the CU's four SIMDs), so
+// wave-uniform state is kept narrow: output positions are 32-bit (k_inflate clamps the
+// capacity below 2^32: lengths are reported as uint32 anyway), and the bit position is a
+// 32-bit offset `rel` into the staged window plus a 64-bit base that changes only when the
+// window is reloaded.
 __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
                             uint32_t *s_in /* LDS, 64 dwords */) {
   uint32_t ext = 0;
@@ -314,18 +319,24 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   }
   const uint64_t nbits = (uint64_t)R.nbytes * 8;
   const uint64_t skip_bits = (uint64_t)R.skip * 8;
-  uint64_t bp = R.consumed;        // bits consumed so far (uniform)
-  uint32_t cw0 = 0xFFFFFFFFu;      // first dword (relative to R.base) held in s_in
-  // match copies in flight: bytes loaded in one round are stored in the next
+  const uint32_t cap = (uint32_t)O.cap;
+  uint8_t *const out = O.out;
+  uint32_t op = (uint32_t)O.opos;  // output position (uniform)
+  uint64_t bp = R.consumed;        // bits consumed so far (uniform); current only while !have
+  int64_t bp0 = 0;                 // bits consumed = bp0 + rel while the window is valid
+  uint32_t rel = 0;                // bit offset of the current position in the window
+  uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
+  bool have = false;
+  // match copies in flight: bytes loaded in one round are stored in the next (plen 0: free)
   constexpr int kPend = 4;
-  uint32_t pend_n = 0, pval[kPend] = {0, 0, 0, 0}, plen[kPend] = {0, 0, 0, 0};
-  uint64_t pdst[kPend] = {0, 0, 0, 0};
+  uint32_t pval[kPend] = {0, 0, 0, 0}, plen[kPend] = {0, 0, 0, 0}, pdst[kPend] = {0, 0, 0, 0};
+  uint32_t pend_lo = 0xFFFFFFFFu;  // lowest output position with a store in flight
   for (;;) {
-    const uint64_t absbit = skip_bits + bp;
-    const uint32_t dw = (uint32_t)(absbit >> 5);
-    if (cw0 == 0xFFFFFFFFu || dw < cw0 || dw + 6 >= cw0 + 64) {
+    if (!have || rel >= 58 * 32) {
+      if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
+      const uint64_t absbit = skip_bits + bp;
+      const uint32_t cw0 = (uint32_t)(absbit >> 5);  // first dword (relative to R.base) held in s_in
       __syncthreads();
-      cw0 = dw;
       const uint64_t first = ((uint64_t)cw0 + lane) * 4;
       const uint64_t end = (uint64_t)R.skip + R.nbytes;
       uint32_t x = 0;
@@ -335,9 +346,14 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       }
       s_in[lane] = x;
       __syncthreads();
+      rel = (uint32_t)absbit & 31;
+      bp0 = (int64_t)bp - (int64_t)rel;
+      const int64_t l = (int64_t)nbits - bp0;
+      lim = l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
+      have = true;
     }
     // ---- every lane decodes the token starting `lane` bits ahead
-    const uint32_t bit = (uint32_t)(absbit - (uint64_t)cw0 * 32) + lane;
+    const uint32_t bit = rel + lane;
     const uint32_t di = bit >> 5, sh = bit & 31;
     const uint32_t w0 = s_in[di], w1 = s_in[di + 1], w2 = s_in[di + 2];
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
@@ -365,25 +381,24 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
     const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
 
-    // ---- walk the chain of real tokens from lane 0; my_off = output offset of each.
-    // A token the walk cannot pass (slow / invalid / end of block) advances by 64.
+    // ---- walk the chain of real tokens from lane 0.  acc = bits walked | output bytes << 8;
+    // each token's lane receives acc as it was at its start.  A token the walk cannot pass
+    // (slow / invalid / end of block) advances by 64 bits.
     const bool hard = slow | bad | is_eob;
     const uint32_t P = hard ? 64u : (tok_bits | (out_len << 8));
-    unsigned long long valid = 0;
-    uint32_t k = 0, run = 0, my_off = 0;
+    uint32_t acc = 0, k = 0, my_acc = 0xFFFFFFFFu;
     do {
-      const uint32_t p = __builtin_amdgcn_readlane(P, k);
-      valid |= 1ull << k;
-      my_off = lane == k ? run : my_off;
-      run += p >> 8;
-      k += p & 0xff;
+      my_acc = lane == k ? acc : my_acc;
+      acc += __builtin_amdgcn_readlane(P, k);
+      k = acc & 0xff;
     } while (k < 64);
-    const bool is_tok = (valid >> lane) & 1;
+    const bool is_tok = my_acc != 0xFFFFFFFFu;
+    const uint32_t my_off = my_acc >> 8;
     // ---- stop events, in the reference's order of checks for one token
-    const uint64_t my_pos = O.opos + my_off;
-    const bool err11 = is_len & ((uint64_t)dist > my_pos + ext);            // LD:2406-2410
-    const bool full = my_pos + out_len > O.cap;
-    const bool exh = bp + lane + tok_bits > nbits;                          // LD:2428
+    const uint32_t my_pos = op + my_off;
+    const bool err11 = is_len & (dist > my_pos + ext);  // LD:2406-2410
+    const bool full = my_pos + out_len > cap;
+    const bool exh = bit + tok_bits > lim;              // LD:2428
     const unsigned long long stops = __ballot(is_tok & (hard | err11 | full | exh));
     const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
     const bool commit = is_tok & (lane < first);
@@ -391,13 +406,15 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // every store issued before this point is complete: all output below `fenced` is readable
-    const uint64_t fenced = pend_n ? pdst[0] : O.opos;
+    const uint32_t fenced = pend_lo < op ? pend_lo : op;
 #pragma unroll
-    for (int q = 0; q < kPend; q++)
-      if (q < (int)pend_n && lane < plen[q]) O.out[pdst[q] + lane] = (uint8_t)pval[q];
-    pend_n = 0;
+    for (int q = 0; q < kPend; q++) {
+      if (lane < plen[q]) out[pdst[q] + lane] = (uint8_t)pval[q];
+      plen[q] = 0;
+    }
+    pend_lo = 0xFFFFFFFFu;
     // ---- literals of this round
-    if (commit & is_lit) O.out[my_pos] = (uint8_t)sym;
+    if (commit & is_lit) out[my_pos] = (uint8_t)sym;
     // ---- matches of this round
     const bool cm = commit & is_len;
     unsigned long long mm = __ballot(cm);
@@ -406,34 +423,42 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       // nothing in flight (this also excludes every self-overlapping match, dist < len)
       const bool near = cm & (my_pos + mlen > fenced + dist);
       if (__ballot(near) == 0) {
-        do {
+        // the first kPend of them: load now (one lane per byte), store in the next round
+#pragma unroll
+        for (int q = 0; q < kPend; q++) {
+          if (mm) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+            const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+            const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
+            if (len <= kWave) {
+              if (lane < len) {
+                const uint32_t a = dst + lane;
+                pval[q] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+              }
+              plen[q] = len;
+              pdst[q] = dst;
+              pend_lo = pend_lo < dst ? pend_lo : dst;
+            } else {
+              for (uint32_t i = lane; i < len; i += kWave) {
+                const uint32_t a = dst + i;
+                out[a] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+              }
+            }
+          }
+        }
+        while (mm) {
           const uint32_t j = (uint32_t)__builtin_ctzll(mm);
           mm &= mm - 1;
           const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
           const uint32_t d = __builtin_amdgcn_readlane(dist, j);
-          const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
-          const int64_t src0 = (int64_t)dst - (int64_t)d;
-          if (len <= kWave && pend_n < kPend) {  // load now, store in the next round
-            const int64_t si = src0 + lane;
-            const uint8_t *sp = si < 0 ? O.dict + ((int64_t)O.dlen + si) : O.out + si;
-            // (one load per slot, written straight into the slot's register: a select on the
-            // loaded value would make the wave wait for it here)
-#pragma unroll
-            for (int q = 0; q < kPend; q++)
-              if (q == (int)pend_n) {
-                if (lane < len) pval[q] = *sp;
-                plen[q] = len;
-                pdst[q] = dst;
-              }
-            pend_n++;
-          } else {
-            for (uint32_t i = lane; i < len; i += kWave) {
-              const int64_t si = src0 + i;
-              const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
-              O.out[dst + i] = byte;
-            }
+          const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
+          for (uint32_t i = lane; i < len; i += kWave) {
+            const uint32_t a = dst + i;
+            out[a] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
           }
-        } while (mm);
+        }
       } else {
         // in order, each one seeing everything stored before it
         do {
@@ -441,37 +466,38 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
           mm &= mm - 1;
           const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
           const uint32_t d = __builtin_amdgcn_readlane(dist, j);
-          const uint64_t dst = O.opos + __builtin_amdgcn_readlane(my_off, j);
+          const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          const int64_t src0 = (int64_t)dst - (int64_t)d;
           for (uint32_t i = lane; i < len; i += kWave) {
-            const uint32_t jj = d >= len ? i : (i % d);
-            const int64_t si = src0 + jj;
-            const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
-            O.out[dst + i] = byte;
+            const uint32_t a = dst + (d >= len ? i : (i % d));
+            out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
           }
         } while (mm);
       }
     }
     if (first == 64) {  // the whole window was consumed
-      O.opos += run;
-      bp += k;
+      op += acc >> 8;
+      rel += k;
       continue;
     }
     // ---- a stop: nothing may stay deferred past this round
-    if (pend_n) {
+    if (pend_lo != 0xFFFFFFFFu) {
 #pragma unroll
-      for (int q = 0; q < kPend; q++)
-        if (q < (int)pend_n && lane < plen[q]) O.out[pdst[q] + lane] = (uint8_t)pval[q];
-      pend_n = 0;
+      for (int q = 0; q < kPend; q++) {
+        if (lane < plen[q]) out[pdst[q] + lane] = (uint8_t)pval[q];
+        plen[q] = 0;
+      }
+      pend_lo = 0xFFFFFFFFu;
     }
     // ---- the stopping token
     const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
                         (exh ? 16u : 0u) | (is_eob ? 32u : 0u);
     const uint32_t f = __builtin_amdgcn_readlane(fl, first);
-    O.opos += __builtin_amdgcn_readlane(my_off, first);
-    bp += first;
+    op += __builtin_amdgcn_readlane(my_off, first);
+    O.opos = op;
+    rel += first;
+    bp = (uint64_t)(bp0 + (int64_t)rel);
     if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
       br_seek_bits(R, bp, lane);
       bool eob = false;
@@ -479,6 +505,8 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       if (st != 0) return st;
       if (eob) return 0;
       bp = R.consumed;
+      op = (uint32_t)O.opos;
+      have = false;
       continue;
     }
     R.consumed = bp;
@@ -506,7 +534,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   br_init(R, A.in + off, n, lane);
   OutState O;
   O.out = A.out + (size_t)s * A.out_stride;
-  O.cap = A.out_stride;
+  // (lengths are reported as uint32; positions inside decode_block are 32-bit)
+  O.cap = A.out_stride < 0xFFF00000ull ? A.out_stride : 0xFFF00000ull;
   O.opos = 0;
   O.dict = A.dict;
   O.dlen = A.dlen;

@@ -125,8 +125,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   }
   __syncthreads();
   if (nv == 0 || !B.need_lz) return;  // (stored blocks and huffman_only need V only)
+#ifdef LDH_SORT_STOP
+  if (LDH_SORT_STOP == 1) return;
+#endif
 
   for (int pass = 0; pass < 3; pass++) {
+#ifdef LDH_SORT_STOP
+    if (pass + 1 >= LDH_SORT_STOP) return;
+#endif
     const uint32_t shift = 2 - pass;  // digit of v is V[v + shift]
     const uint32_t *src = pass == 1 ? bufA : bufB;
     uint32_t *dst = pass == 1 ? bufB : bufA;
@@ -145,13 +151,22 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     // ones of them, so (wave, sub-round, lane) order is element order and ranks stay stable.
     constexpr uint32_t kTileElems = kSortThreads * kSortItems;
     const uint32_t ntiles = (nv + kTileElems - 1) / kTileElems;
+    // (the next tile's elements are fetched before this tile's scattered stores are issued:
+    // behind them in the memory pipeline the loads would wait for all of them to drain)
+    uint32_t en[kSortItems];
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+      const uint32_t idx = wave * (64 * kSortItems) + lane + j * 64;
+      en[j] = idx < nv ? (pass == 0 ? idx : src[idx]) : 0xFFFFFFFFu;
+    }
     for (uint32_t tile = 0; tile < ntiles; tile++) {
       const uint32_t base_idx = tile * kTileElems + wave * (64 * kSortItems) + lane;
       uint32_t e[kSortItems], d[kSortItems], lrank[kSortItems];
 #pragma unroll
       for (int j = 0; j < kSortItems; j++) {
-        const uint32_t idx = base_idx + j * 64;
-        e[j] = idx < nv ? (pass == 0 ? idx : src[idx]) : 0xFFFFFFFFu;
+        e[j] = en[j];
+        const uint32_t idx = base_idx + kTileElems + j * 64;
+        en[j] = idx < nv ? (pass == 0 ? idx : src[idx]) : 0xFFFFFFFFu;
       }
 #pragma unroll
       for (int j = 0; j < kSortItems; j++) d[j] = e[j] != 0xFFFFFFFFu ? VBYTE(e[j] + shift) : 0;
@@ -268,8 +283,14 @@ constexpr int kMatchThreads = 1024;
 constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
 constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
 constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
-constexpr uint32_t kMatchSteps = 8;   // chain steps between two looks at the long paths
-constexpr uint32_t kRefillIdle = 16;  // lanes that must be idle before the wave fetches new positions
+#ifndef LDH_MATCH_STEPS
+#define LDH_MATCH_STEPS 8
+#endif
+#ifndef LDH_REFILL_IDLE
+#define LDH_REFILL_IDLE 16
+#endif
+constexpr uint32_t kMatchSteps = LDH_MATCH_STEPS;  // chain steps between two looks at the long paths
+constexpr uint32_t kRefillIdle = LDH_REFILL_IDLE;  // lanes that must be idle before the wave fetches new positions
 
 // One lane works on one position at a time and walks its chain one candidate per loop
 // trip; lanes whose chain has ended take the next position of the tile from a workgroup
