@@ -26,7 +26,7 @@ template <int LUT_BITS, int NSYM>
 struct DecTabT {
   static constexpr int kBits = LUT_BITS;
   static constexpr int kSize = 1 << LUT_BITS;
-  uint16_t lut[kSize];     // (sym << 4) | len for codes of <= kBits bits; 0 = slow path
+  uint16_t lut[kSize];     // entry for codes of <= kBits bits (see lut_entry); 0 = slow path
   uint16_t symbols[NSYM];  // puff order: by (length, symbol)
   uint32_t counts[16];
   uint32_t offs[16];
@@ -35,6 +35,33 @@ struct DecTabT {
 };
 using LitTab = DecTabT<kLutBits, 288>;
 using DistTab = DecTabT<9, 32>;
+
+// Lookup entries carry what the lane-parallel decoder needs, ready to use (computing base and
+// extra-bit count of LD:188-240 from the symbol cost a fifth of its vector instructions):
+//   kLutPlain   (sym << 4) | bits                                   code-length alphabet
+//   kLutLitLen  literal / end of block / 286-287:  (sym << 4) | bits, sym 286.. stored as 511
+//               length symbol:  1 << 15 | (base - 3) << 7 | extra_bits << 4 | bits
+//   kLutDist    bad << 10 | mant << 8 | extra_bits << 4 | bits:  dist = 1 + (mant << eb) + extra;
+//               bad = symbols 30, 31
+enum { kLutPlain = 0, kLutLitLen = 1, kLutDist = 2 };
+__device__ inline uint32_t lut_entry(int mode, uint32_t sym, uint32_t bits) {
+  if (mode == kLutLitLen) {
+    if (sym > 285) return (511u << 4) | bits;
+    if (sym > 256) {
+      const uint32_t ls = sym - 257;
+      const uint32_t eb = (ls < 8 || ls == 28) ? 0u : (ls >> 2) - 1;
+      const uint32_t b3 = ls < 8 ? ls : (ls == 28 ? 255u : (4u + (ls & 3)) << eb);
+      return (1u << 15) | (b3 << 7) | (eb << 4) | bits;
+    }
+  } else if (mode == kLutDist) {
+    const uint32_t bad = sym > 29 ? 1u : 0u;
+    const uint32_t dsc = bad ? 29u : sym;
+    const uint32_t eb = dsc < 4 ? 0u : (dsc >> 1) - 1;
+    const uint32_t mant = dsc < 4 ? dsc : 2u + (dsc & 1);
+    return (bad << 10) | (mant << 8) | (eb << 4) | bits;
+  }
+  return (sym << 4) | bits;
+}
 
 struct InflateArgs {
   const uint8_t *in;
@@ -133,7 +160,7 @@ __device__ inline void br_align(BitReader &R, uint32_t lane) {  // SkipToByteBou
 // < 0 over-subscribed.  Called by the whole wavefront (block = one wavefront).
 template <class DecTab>
 __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bitlen, int lut_bits,
-                           uint32_t lane) {
+                           uint32_t lane, int mode) {
   if (lane < 16) {
     T.counts[lane] = 0;
     T.running[lane] = 0;
@@ -180,7 +207,8 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
       if ((int)l <= lut_bits) {
         const uint32_t c = T.first[l] + in_len;
         const uint32_t r = __brev(c) >> (32 - l);
-        for (uint32_t k = r; k < (1u << lut_bits); k += (1u << l)) T.lut[k] = (uint16_t)((i << 4) | l);
+        const uint16_t ent = (uint16_t)lut_entry(mode, (uint32_t)i, l);
+        for (uint32_t k = r; k < (1u << lut_bits); k += (1u << l)) T.lut[k] = ent;
       }
     }
     __syncthreads();
@@ -194,7 +222,9 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
 template <class DecTab>
 __device__ inline int decode_sym(const DecTab &T, int lut_bits, BitReader &R, uint32_t lane) {
   br_refill(R, lane);
-  const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t)T.lut[R.bitbuf & ((1u << lut_bits) - 1u)]);
+  // lut_bits 0: a table with packed entries (kLutLitLen / kLutDist); take the canonical walk
+  const uint32_t e =
+      lut_bits ? __builtin_amdgcn_readfirstlane((uint32_t)T.lut[R.bitbuf & ((1u << lut_bits) - 1u)]) : 0u;
   int sym;
   uint32_t len;
   if (e) {
@@ -360,24 +390,21 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
     const uint64_t win = ((uint64_t)hi << 32) | lo;
     const uint32_t e = LT.lut[lo & (LitTab::kSize - 1)];
-    const uint32_t sym = e >> 4, l1 = e & 15;
-    const bool is_lit = sym < 256, is_eob = sym == 256, is_len = sym > 256;
+    const uint32_t l1 = e & 15;
+    const bool is_len = (e >> 15) != 0;
+    const uint32_t sym = (e >> 4) & 511;  // meaningful when !is_len
+    const bool is_lit = !is_len & (sym < 256), is_eob = !is_len & (sym == 256);
     bool slow = e == 0;
-    bool bad = sym > 285;
-    const uint32_t ls = is_len ? (sym > 285 ? 28u : sym - 257) : 0u;
-    const uint32_t leb = (ls < 8 || ls == 28) ? 0u : (ls >> 2) - 1;
-    const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4u + (ls & 3)) << leb));
-    const uint32_t mlen = lbase + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
+    bool bad = !is_len & (sym == 511);
+    const uint32_t leb = is_len ? (e >> 4) & 7 : 0u;
+    const uint32_t mlen = 3 + ((e >> 7) & 255) + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
     const uint32_t t = l1 + leb;
     const uint32_t din = (uint32_t)(win >> t);
     const uint32_t e2 = DT.lut[din & (DistTab::kSize - 1)];
-    const uint32_t dsym = e2 >> 4, l2 = e2 & 15;
+    const uint32_t l2 = e2 & 15, deb = (e2 >> 4) & 15;
     slow = slow | (is_len & (e2 == 0));
-    bad = bad | (is_len & (dsym > 29));
-    const uint32_t dsc = dsym > 29 ? 29u : dsym;
-    const uint32_t deb = dsc < 4 ? 0u : (dsc >> 1) - 1;
-    const uint32_t dbase = dsc < 4 ? dsc + 1 : 1 + ((2u + (dsc & 1)) << deb);
-    const uint32_t dist = dbase + ((din >> l2) & ((1u << deb) - 1u));
+    bad = bad | (is_len & ((e2 >> 10) != 0));
+    const uint32_t dist = 1 + (((e2 >> 8) & 3) << deb) + ((din >> l2) & ((1u << deb) - 1u));
     const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
     const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
 
@@ -501,7 +528,7 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
       br_seek_bits(R, bp, lane);
       bool eob = false;
-      const int st = decode_one(LT, DT, LitTab::kBits, DistTab::kBits, R, O, ext, lane, &eob);
+      const int st = decode_one(LT, DT, 0, 0, R, O, ext, lane, &eob);
       if (st != 0) return st;
       if (eob) return 0;
       bp = R.consumed;
@@ -584,8 +611,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           for (int i = lane; i < 288; i += kWave) lens[i] = (uint8_t)fixed_lit_bits(i);
           if (lane < 32) lens[288 + lane] = 5;
           __syncthreads();
-          build_table(LT, lens, 288, 9, LitTab::kBits, lane);
-          build_table(DT, lens + 288, 32, 5, DistTab::kBits, lane);
+          build_table(LT, lens, 288, 9, LitTab::kBits, lane, kLutLitLen);
+          build_table(DT, lens + 288, 32, 5, DistTab::kBits, lane, kLutDist);
           fixed_ready = 1;
         }
         status = decode_block(LT, DT, R, O, lane, s_in);
@@ -604,7 +631,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           if (lane == 0) lens[order[i]] = (uint8_t)v;
         }
         __syncthreads();
-        if (build_table(DT, lens, 19, 7, 7, lane) != 0) { status = -4; break; }
+        if (build_table(DT, lens, 19, 7, 7, lane, kLutPlain) != 0) { status = -4; break; }
         __syncthreads();
         for (int i = lane; i < 320; i += kWave) lens[i] = 0;
         __syncthreads();
@@ -642,9 +669,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         __syncthreads();
         if (lane < 32) lens[320 + lane] = dl;
         __syncthreads();
-        int err = build_table(LT, lens, (int)nlen, 15, LitTab::kBits, lane);
+        int err = build_table(LT, lens, (int)nlen, 15, LitTab::kBits, lane, kLutLitLen);
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
-        err = build_table(DT, lens + 320, (int)ndist, 15, DistTab::kBits, lane);
+        err = build_table(DT, lens + 320, (int)ndist, 15, DistTab::kBits, lane, kLutDist);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
         status = decode_block(LT, DT, R, O, lane, s_in);
       } else {
