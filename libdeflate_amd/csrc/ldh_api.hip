@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "k_huffman.h"
@@ -86,7 +87,7 @@ int fail(int code, const char *fmt, ...) {
 int ensure(DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
-    hipStreamSynchronize(g_stream);
+    hipDeviceSynchronize();  // (the host-pointer entry points keep copies in flight on other streams)
     hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
@@ -343,6 +344,127 @@ int upload_inputs(const uint8_t *in_base, const uint64_t *in_off, size_t count) 
   return 0;
 }
 
+// ---- host-pointer batches: pinned staging, copies overlapped with kernels -----
+// A batch is cut into pieces of about piece_bytes() (64 MiB).  Piece k is gathered into pinned memory by
+// a few host threads, copied in on one stream, processed on g_stream, and its results are
+// copied out (only the bytes produced: a 2D copy as wide as the piece's longest result) on a
+// third stream and scattered to the caller's slots by the host threads -- while the kernels
+// of piece k+1 run.  Compression alternates two slots; decompression, whose results are the
+// large side, rotates three, so that the copy-out of piece k-1 also overlaps the scatter of
+// piece k-2.
+// (LDH_PIECE_KB: test hook, so that small batches are cut into many pieces too)
+size_t piece_bytes() {
+  const char *e = getenv("LDH_PIECE_KB");
+  const size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : 65536;
+  return std::max<size_t>(kb, 1) << 10;
+}
+// k_inflate runs one wavefront per stream and a stream takes milliseconds however few there are,
+// so decompression wants thousands of streams per piece
+size_t inflate_piece_bytes() { return 4 * piece_bytes(); }
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+struct Slot {
+  PinBuf pin_in, pin_off, pin_out, pin_small;
+  DevBuf d_in, d_off, d_out, d_len, d_a8, d_a32a, d_a32b;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+  size_t w = 0;  // row width of the result copy in flight
+};
+Slot g_slot[3];
+hipStream_t g_s_in = nullptr, g_s_out = nullptr;
+
+int ensure_pinned(PinBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    hipDeviceSynchronize();
+    hipHostFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t want = bytes + bytes / 8 + 4096;
+  const hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(LDH_E_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+  b.cap = want;
+  return 0;
+}
+
+int pipeline_init() {
+  if (g_s_in) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&g_s_in, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&g_s_out, hipStreamNonBlocking));
+  for (Slot &sl : g_slot) {
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+  }
+  return 0;
+}
+
+void pipeline_free() {
+  for (Slot &sl : g_slot) {
+    for (PinBuf *b : {&sl.pin_in, &sl.pin_off, &sl.pin_out, &sl.pin_small}) {
+      if (b->p) hipHostFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+    for (DevBuf *b : {&sl.d_in, &sl.d_off, &sl.d_out, &sl.d_len, &sl.d_a8, &sl.d_a32a, &sl.d_a32b}) {
+      if (b->p) hipFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+    if (sl.ev_in) hipEventDestroy(sl.ev_in);
+    if (sl.ev_done) hipEventDestroy(sl.ev_done);
+    if (sl.ev_out) hipEventDestroy(sl.ev_out);
+    sl.ev_in = sl.ev_done = sl.ev_out = nullptr;
+  }
+  if (g_s_in) hipStreamDestroy(g_s_in);
+  if (g_s_out) hipStreamDestroy(g_s_out);
+  g_s_in = g_s_out = nullptr;
+}
+
+// an entry point that returns early (an error) must not leave copies or kernels in flight on
+// the slots the next call will reuse
+struct DrainGuard {
+  bool clean = false;
+  ~DrainGuard() {
+    if (!clean) hipDeviceSynchronize();
+  }
+};
+
+unsigned copy_threads() {
+  static unsigned n = 0;
+  if (!n) {
+    const char *e = getenv("LDH_COPY_THREADS");
+    n = e ? (unsigned)strtoul(e, nullptr, 10) : 8;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && n > hw) n = hw;
+    if (n < 1) n = 1;
+  }
+  return n;
+}
+// f(lo, hi) over [0, n) on the copy threads (inline when the job is small)
+template <class F>
+void par_ranges(size_t n, size_t bytes, F f) {
+  const unsigned T = bytes < (2u << 20) ? 1u : copy_threads();
+  if (T <= 1 || n < 2) {
+    f((size_t)0, n);
+    return;
+  }
+  const size_t per = (n + T - 1) / T;
+  std::vector<std::thread> th;
+  for (size_t lo = per; lo < n; lo += per) th.emplace_back([=] { f(lo, std::min(n, lo + per)); });
+  f((size_t)0, std::min(n, per));
+  for (auto &t : th) t.join();
+}
+void par_memcpy(void *dst, const void *src, size_t bytes) {
+  constexpr size_t kBlk = 1u << 20;
+  par_ranges((bytes + kBlk - 1) / kBlk, bytes, [=](size_t lo, size_t hi) {
+    const size_t a = lo * kBlk, b = std::min(bytes, hi * kBlk);
+    memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a);
+  });
+}
+
 }  // namespace
 
 // =============================================================================
@@ -367,7 +489,8 @@ int ldh_init(int device) {
 void ldh_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_device < 0) return;
-  hipStreamSynchronize(g_stream);
+  hipDeviceSynchronize();
+  pipeline_free();
   for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_bufC, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
                     &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b, &g_codec_tmp}) {
     if (b->p) hipFree(b->p);
@@ -516,6 +639,8 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
   if (count == 0) return 0;
   if (level < -1 || level > 9) return fail(LDH_E_ARG, "level must be -1..9 (got %d)", level);
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  if (int rc = pipeline_init()) return rc;
+  DrainGuard drain;
   // group streams by resolved level (LD:1782-1790) and by size class so that the
   // per-stream workspace (sized by the longest stream of a launch) is not wasted
   struct Group {
@@ -542,52 +667,100 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
     g->max_len = std::max(g->max_len, n);
   }
   for (auto &g : groups) {
-    const size_t gc = g.idx.size();
     const int lv = g.level / 32;
     if (out_stride < ldh_compress_bound(g.max_len))
       return fail(LDH_E_CAPACITY, "out_stride %zu < ldh_compress_bound(%zu)", out_stride, g.max_len);
-    // gather this group's streams contiguously
-    std::vector<uint64_t> off(gc + 1);
-    uint64_t tot = 0;
-    for (size_t i = 0; i < gc; i++) {
-      off[i] = tot;
-      tot += in_off[g.idx[i] + 1] - in_off[g.idx[i]];
-    }
-    off[gc] = tot;
-    const bool contiguous = (g.idx.back() - g.idx.front() + 1 == gc);
-    if (int rc = ensure(g_h_in, tot + 64)) return rc;
-    if (int rc = ensure(g_h_off, (gc + 1) * 8)) return rc;
-    if (int rc = ensure(g_h_out, gc * out_stride)) return rc;
-    if (int rc = ensure(g_h_len, gc * 4 + 64)) return rc;
-    if (int rc = ensure(g_h_aux8, gc + 64)) return rc;
-    if (contiguous) {
-      if (tot) HIPCHK(hipMemcpyAsync(g_h_in.p, in_base + in_off[g.idx[0]], tot, hipMemcpyHostToDevice, g_stream));
-    } else {
-      for (size_t i = 0; i < gc; i++) {
-        const size_t n = in_off[g.idx[i] + 1] - in_off[g.idx[i]];
-        if (n)
-          HIPCHK(hipMemcpyAsync((uint8_t *)g_h_in.p + off[i], in_base + in_off[g.idx[i]], n, hipMemcpyHostToDevice,
-                                g_stream));
+    // pieces [first, last) of g.idx
+    struct Piece {
+      size_t first, last;
+      uint64_t bytes;
+    };
+    std::vector<Piece> pieces;
+    const size_t piece = piece_bytes();
+    for (size_t i = 0; i < g.idx.size();) {
+      Piece pc{i, i, 0};
+      while (pc.last < g.idx.size() && (pc.last == pc.first || pc.bytes < piece)) {
+        pc.bytes += in_off[g.idx[pc.last] + 1] - in_off[g.idx[pc.last]];
+        pc.last++;
       }
+      pieces.push_back(pc);
+      i = pc.last;
     }
-    HIPCHK(hipMemcpyAsync(g_h_off.p, off.data(), (gc + 1) * 8, hipMemcpyHostToDevice, g_stream));
-    if (int rc = compress_dev_locked((const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, gc, g.max_len, fmt, lv,
-                                     strategy, dict, (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
-                                     (uint8_t *)g_h_aux8.p))
-      return rc;
-    std::vector<uint32_t> lens(gc);
-    std::vector<uint8_t> pads(gc);
-    HIPCHK(hipMemcpyAsync(lens.data(), g_h_len.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipMemcpyAsync(pads.data(), g_h_aux8.p, gc, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipStreamSynchronize(g_stream));
-    for (size_t i = 0; i < gc; i++) {
-      out_len[g.idx[i]] = lens[i];
-      pad_bits[g.idx[i]] = pads[i];
-      HIPCHK(hipMemcpyAsync(out_base + g.idx[i] * out_stride, (uint8_t *)g_h_out.p + i * out_stride, lens[i],
-                            hipMemcpyDeviceToHost, g_stream));
+    auto finish = [&](size_t k) -> int {  // results of piece k to the caller
+      Slot &sl = g_slot[k & 1];
+      const Piece &pc = pieces[k];
+      const size_t gc = pc.last - pc.first;
+      HIPCHK(hipEventSynchronize(sl.ev_done));
+      const uint32_t *lens = (const uint32_t *)sl.pin_small.p;
+      const uint8_t *pads = (const uint8_t *)sl.pin_small.p + gc * 4;
+      size_t w = 0;
+      for (size_t i = 0; i < gc; i++) w = std::max<size_t>(w, lens[i]);
+      w = std::min(round_up(w, 16), out_stride);
+      if (int rc = ensure_pinned(sl.pin_out, gc * w + 64)) return rc;
+      if (w) {
+        HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, g_s_out));
+        HIPCHK(hipStreamSynchronize(g_s_out));
+      }
+      const uint8_t *rows = (const uint8_t *)sl.pin_out.p;
+      const size_t *idx = g.idx.data() + pc.first;
+      par_ranges(gc, gc * w, [=](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+          out_len[idx[i]] = lens[i];
+          pad_bits[idx[i]] = pads[i];
+          memcpy(out_base + idx[i] * out_stride, rows + i * w, lens[i]);
+        }
+      });
+      return 0;
+    };
+    for (size_t k = 0; k < pieces.size(); k++) {
+      Slot &sl = g_slot[k & 1];
+      const Piece &pc = pieces[k];
+      const size_t gc = pc.last - pc.first;
+      // (piece k-2, the last user of this slot, was finished before piece k-1 was enqueued)
+      if (int rc = ensure_pinned(sl.pin_in, pc.bytes + 64)) return rc;
+      if (int rc = ensure_pinned(sl.pin_off, (gc + 1) * 8)) return rc;
+      if (int rc = ensure_pinned(sl.pin_small, gc * 5 + 64)) return rc;
+      if (int rc = ensure(sl.d_in, pc.bytes + 64)) return rc;
+      if (int rc = ensure(sl.d_off, (gc + 1) * 8)) return rc;
+      if (int rc = ensure(sl.d_out, gc * out_stride)) return rc;
+      if (int rc = ensure(sl.d_len, gc * 4 + 64)) return rc;
+      if (int rc = ensure(sl.d_a8, gc + 64)) return rc;
+      uint64_t *off = (uint64_t *)sl.pin_off.p;
+      uint64_t tot = 0;
+      size_t max_len = 0;
+      for (size_t i = 0; i < gc; i++) {
+        off[i] = tot;
+        const size_t n = in_off[g.idx[pc.first + i] + 1] - in_off[g.idx[pc.first + i]];
+        tot += n;
+        max_len = std::max(max_len, n);
+      }
+      off[gc] = tot;
+      const size_t *idx = g.idx.data() + pc.first;
+      if (idx[gc - 1] - idx[0] + 1 == gc) {
+        par_memcpy(sl.pin_in.p, in_base + in_off[idx[0]], tot);
+      } else {
+        uint8_t *dst = (uint8_t *)sl.pin_in.p;
+        par_ranges(gc, tot, [=](size_t lo, size_t hi) {
+          for (size_t i = lo; i < hi; i++) memcpy(dst + off[i], in_base + in_off[idx[i]], off[i + 1] - off[i]);
+        });
+      }
+      if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, g_s_in));
+      HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, g_s_in));
+      HIPCHK(hipEventRecord(sl.ev_in, g_s_in));
+      HIPCHK(hipStreamWaitEvent(g_stream, sl.ev_in, 0));
+      if (int rc = compress_dev_locked((const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, gc, max_len, fmt, lv,
+                                       strategy, dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
+                                       (uint8_t *)sl.d_a8.p))
+        return rc;
+      HIPCHK(hipMemcpyAsync(sl.pin_small.p, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
+      HIPCHK(hipMemcpyAsync((uint8_t *)sl.pin_small.p + gc * 4, sl.d_a8.p, gc, hipMemcpyDeviceToHost, g_stream));
+      HIPCHK(hipEventRecord(sl.ev_done, g_stream));
+      if (k > 0)
+        if (int rc = finish(k - 1)) return rc;
     }
-    HIPCHK(hipStreamSynchronize(g_stream));
+    if (int rc = finish(pieces.size() - 1)) return rc;
   }
+  drain.clean = true;
   return 0;
 }
 
@@ -598,24 +771,101 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
   if (int rc = check_init()) return rc;
   if (count == 0) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
-  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
-  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
-  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
-  if (int rc = ensure(g_h_aux32a, count * 4 + 64)) return rc;
-  if (int rc = ensure(g_h_aux32b, count * 4 + 64)) return rc;
-  if (int rc = decompress_dev_locked((const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, nullptr, 0, count, fmt, dict,
-                                     (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
-                                     (uint32_t *)g_h_aux32a.p, (int32_t *)g_h_aux32b.p))
-    return rc;
-  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(bytes_left, g_h_aux32a.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(status, g_h_aux32b.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
-  for (size_t s = 0; s < count; s++)
-    if (status[s] == 0 && out_len[s])
-      HIPCHK(hipMemcpyAsync(out_base + s * out_stride, (uint8_t *)g_h_out.p + s * out_stride, out_len[s],
-                            hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  if (int rc = pipeline_init()) return rc;
+  DrainGuard drain;
+  struct Piece {
+    size_t first, last;
+  };
+  std::vector<Piece> pieces;
+  const size_t piece = inflate_piece_bytes();
+  for (size_t i = 0; i < count;) {
+    size_t j = i + 1;
+    while (j < count && (j - i + 1) * out_stride <= piece && in_off[j + 1] - in_off[i] <= piece) j++;
+    pieces.push_back({i, j});
+    i = j;
+  }
+  auto start_out = [&](size_t k) -> int {  // piece k is done on the device: start copying its results out
+    Slot &sl = g_slot[k % 3];
+    const Piece &pc = pieces[k];
+    const size_t gc = pc.last - pc.first;
+    HIPCHK(hipEventSynchronize(sl.ev_done));
+    const uint32_t *lens = (const uint32_t *)sl.pin_small.p;
+    const int32_t *st = (const int32_t *)((const uint8_t *)sl.pin_small.p + gc * 8);
+    memcpy(out_len + pc.first, lens, gc * 4);
+    memcpy(bytes_left + pc.first, (const uint8_t *)sl.pin_small.p + gc * 4, gc * 4);
+    memcpy(status + pc.first, st, gc * 4);
+    size_t w = 0;
+    for (size_t i = 0; i < gc; i++)
+      if (st[i] == 0) w = std::max<size_t>(w, lens[i]);
+    w = std::min(round_up(w, 16), out_stride);
+    sl.w = w;
+    if (!w) return 0;
+    if (int rc = ensure_pinned(sl.pin_out, gc * w + 64)) return rc;
+    if (w == out_stride)
+      HIPCHK(hipMemcpyAsync(sl.pin_out.p, sl.d_out.p, gc * w, hipMemcpyDeviceToHost, g_s_out));
+    else
+      HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, g_s_out));
+    HIPCHK(hipEventRecord(sl.ev_out, g_s_out));
+    return 0;
+  };
+  auto scatter = [&](size_t k) -> int {  // results of piece k from pinned memory to the caller's slots
+    Slot &sl = g_slot[k % 3];
+    const Piece &pc = pieces[k];
+    const size_t gc = pc.last - pc.first, w = sl.w;
+    if (!w) return 0;
+    HIPCHK(hipEventSynchronize(sl.ev_out));
+    const uint32_t *lens = (const uint32_t *)sl.pin_small.p;
+    const int32_t *st = (const int32_t *)((const uint8_t *)sl.pin_small.p + gc * 8);
+    const uint8_t *rows = (const uint8_t *)sl.pin_out.p;
+    uint8_t *dst = out_base + pc.first * out_stride;
+    par_ranges(gc, gc * w, [=](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++)
+        if (st[i] == 0 && lens[i]) memcpy(dst + i * out_stride, rows + i * w, lens[i]);
+    });
+    return 0;
+  };
+  for (size_t k = 0; k < pieces.size(); k++) {
+    Slot &sl = g_slot[k % 3];  // (its last user, piece k-3, was scattered before piece k-1 was enqueued)
+    const Piece &pc = pieces[k];
+    const size_t gc = pc.last - pc.first;
+    const uint64_t base = in_off[pc.first], tot = in_off[pc.last] - base;
+    if (int rc = ensure_pinned(sl.pin_in, tot + 64)) return rc;
+    if (int rc = ensure_pinned(sl.pin_off, (gc + 1) * 8)) return rc;
+    if (int rc = ensure_pinned(sl.pin_small, gc * 12 + 64)) return rc;
+    if (int rc = ensure(sl.d_in, tot + 64)) return rc;
+    if (int rc = ensure(sl.d_off, (gc + 1) * 8)) return rc;
+    if (int rc = ensure(sl.d_out, gc * out_stride + 64)) return rc;
+    if (int rc = ensure(sl.d_len, gc * 4 + 64)) return rc;
+    if (int rc = ensure(sl.d_a32a, gc * 4 + 64)) return rc;
+    if (int rc = ensure(sl.d_a32b, gc * 4 + 64)) return rc;
+    // offsets are re-based to start at 0 so that the device copy of the data is aligned
+    uint64_t *off = (uint64_t *)sl.pin_off.p;
+    for (size_t i = 0; i <= gc; i++) off[i] = in_off[pc.first + i] - base;
+    par_memcpy(sl.pin_in.p, in_base + base, tot);
+    if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, g_s_in));
+    HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, g_s_in));
+    HIPCHK(hipEventRecord(sl.ev_in, g_s_in));
+    HIPCHK(hipStreamWaitEvent(g_stream, sl.ev_in, 0));
+    if (int rc = decompress_dev_locked((const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, nullptr, 0, gc, fmt,
+                                       dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
+                                       (uint32_t *)sl.d_a32a.p, (int32_t *)sl.d_a32b.p))
+      return rc;
+    uint8_t *small = (uint8_t *)sl.pin_small.p;
+    HIPCHK(hipMemcpyAsync(small, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(small + gc * 4, sl.d_a32a.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(small + gc * 8, sl.d_a32b.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipEventRecord(sl.ev_done, g_stream));
+    if (k > 0)
+      if (int rc = start_out(k - 1)) return rc;
+    if (k > 1)
+      if (int rc = scatter(k - 2)) return rc;
+  }
+  const size_t np = pieces.size();
+  if (int rc = start_out(np - 1)) return rc;
+  if (np > 1)
+    if (int rc = scatter(np - 2)) return rc;
+  if (int rc = scatter(np - 1)) return rc;
+  drain.clean = true;
   return 0;
 }
 

@@ -123,6 +123,39 @@ def test_ragged_batch_default_levels(B):
         assert g == o_compress(s, zlib=True, level=5), len(s)
 
 
+def test_host_batches_in_many_pieces(B, monkeypatch):
+    # the host-pointer entry points cut a batch into pieces (64 MiB) whose copies overlap the kernels of the next
+    # piece; LDH_PIECE_KB shrinks the pieces so that this ragged batch goes through dozens of them, in groups whose
+    # streams are not contiguous (default level: three size classes), with empty, failing and truncated streams
+    v = splitmix64(7, 400)
+    base = golden("totalrp3.txt") + golden("encode_6bit_weakaura.txt")
+    cases = []
+    for i in range(400):
+        n = int(v[i] % 5000) if i % 5 else int(v[i] % 80000)
+        o = int((v[i] >> 20) % (len(base) - n - 1))
+        cases.append(base[o: o + n])
+    cases[17] = b""
+    cases[250] = b""
+    whole = B.compress_batch(cases, level=None)
+    whole5 = B.compress_batch(cases, fmt=1, level=5)
+    monkeypatch.setenv("LDH_PIECE_KB", "16")
+    assert B.compress_batch(cases, level=None) == whole
+    assert B.compress_batch(cases, fmt=1, level=5) == whole5
+    for i in (0, 17, 100, 399):
+        assert whole[i] == o_compress(cases[i]), i
+    comp = [c for c, _ in whole]
+    comp[3] = comp[3][: len(comp[3]) // 2]      # truncated
+    comp[200] = b"\xff" + comp[200]            # invalid block type
+    pieces = B.decompress_batch(comp)
+    monkeypatch.delenv("LDH_PIECE_KB")
+    assert pieces == B.decompress_batch(comp)
+    for i, (raw, g) in enumerate(zip(comp, pieces)):
+        if i in (3, 200):
+            assert g == o_decompress(raw), i
+        else:
+            assert g == (cases[i], 0), i
+
+
 def test_synthetic_configs(B):
     from libdeflate_amd import synth
     text = [r.tobytes() for r in synth.text_streams(6, 131072)]      # BASELINE configs[2] shape
