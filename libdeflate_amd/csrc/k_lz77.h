@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   }
   __syncthreads();
   if (nv == 0 || !B.need_lz) return;  // (stored blocks and huffman_only need V only)
-#ifdef LDH_SORT_STOP
+#ifdef LDH_SORT_STOP  // profiling builds only (-DLDH_SORT_STOP=n: leave after stage n; results are wrong)
   if (LDH_SORT_STOP == 1) return;
 #endif
 
