@@ -231,24 +231,45 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     // Instead: (a) link values in sorted order, coalesced, into the free ping-pong buffer;
     // (b) V is no longer needed, so its LDS holds the links of 65536 positions at a time:
     // scatter there, then copy out in order.
+    // (four elements per thread and trip, loads first: one workgroup per CU has nothing else to
+    // hide their latency with)
     uint16_t *dl = (uint16_t *)bufB;
-    for (uint32_t r = tid; r < nv; r += kSortThreads) {
-      uint32_t dlt = 0;
-      if (r > 0) {
-        const uint32_t v = SRT(r), u = SRT(r - 1);
-        const uint32_t tu = lds_load4((const uint32_t *)ldsV, u) << 8;  // three bytes (V is zero padded)
-        const uint32_t tv = lds_load4((const uint32_t *)ldsV, v) << 8;
-        if (tu == tv && v - u <= kWindow) dlt = v - u;
+    constexpr uint32_t kLinkItems = 4;
+    for (uint32_t r0 = tid; r0 < nv; r0 += kSortThreads * kLinkItems) {
+      uint32_t v[kLinkItems], u[kLinkItems];
+#pragma unroll
+      for (uint32_t j = 0; j < kLinkItems; j++) {
+        const uint32_t r = r0 + j * kSortThreads;
+        v[j] = r < nv ? bufA[r] : 0u;
+        u[j] = (r > 0 && r < nv) ? bufA[r - 1] : 0u;
       }
-      dl[r] = (uint16_t)dlt;
+#pragma unroll
+      for (uint32_t j = 0; j < kLinkItems; j++) {
+        const uint32_t r = r0 + j * kSortThreads;
+        uint32_t dlt = 0;
+        if (r > 0 && r < nv) {
+          const uint32_t tu = lds_load4((const uint32_t *)ldsV, u[j]) << 8;  // three bytes (V is zero padded)
+          const uint32_t tv = lds_load4((const uint32_t *)ldsV, v[j]) << 8;
+          if (tu == tv && v[j] - u[j] <= kWindow) dlt = v[j] - u[j];
+        }
+        if (r < nv) dl[r] = (uint16_t)dlt;
+      }
     }
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
     const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~1u;  // positions whose links fit V's LDS (>= 24, even)
     for (uint32_t h0 = 0; h0 < nv; h0 += H) {
-      for (uint32_t r = tid; r < nv; r += kSortThreads) {
-        const uint32_t v = SRT(r);
-        if (v - h0 < H) l16[v - h0] = dl[r];
+      for (uint32_t r0 = tid; r0 < nv; r0 += kSortThreads * kLinkItems) {
+        uint32_t v[kLinkItems], l[kLinkItems];
+#pragma unroll
+        for (uint32_t j = 0; j < kLinkItems; j++) {
+          const uint32_t r = r0 + j * kSortThreads;
+          v[j] = r < nv ? bufA[r] : 0xFFFFFFFFu;
+          l[j] = r < nv ? dl[r] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kLinkItems; j++)
+          if (v[j] != 0xFFFFFFFFu && v[j] - h0 < H) l16[v[j] - h0] = (uint16_t)l[j];
       }
       __syncthreads();
       const uint32_t cnt = nv - h0 < H ? nv - h0 : H;  // prevd rows are 4-byte aligned (nvp % 16 == 0)
