@@ -49,7 +49,13 @@ __device__ inline uint64_t lds_load8(const uint32_t *w, uint32_t byteoff) {
 // ------------------------------------------------------------------ k_sort_links
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
-constexpr int kSortItems = 4;  // elements per thread per tile
+#ifndef LDH_SORT_ITEMS
+#define LDH_SORT_ITEMS 8
+#endif
+#ifndef LDH_LINK_ITEMS
+#define LDH_LINK_ITEMS 8
+#endif
+constexpr int kSortItems = LDH_SORT_ITEMS;  // elements per thread per tile
 
 // exclusive scan of 256 values held by threads 0..255 (one value each); result in out[256]
 __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *out, uint32_t *wave_tot) {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     // (four elements per thread and trip, loads first: one workgroup per CU has nothing else to
     // hide their latency with)
     uint16_t *dl = (uint16_t *)bufB;
-    constexpr uint32_t kLinkItems = 4;
+    constexpr uint32_t kLinkItems = LDH_LINK_ITEMS;
     for (uint32_t r0 = tid; r0 < nv; r0 += kSortThreads * kLinkItems) {
       uint32_t v[kLinkItems], u[kLinkItems];
 #pragma unroll
