@@ -674,15 +674,19 @@ __global__ __launch_bounds__(kParseThreads) void k_parse_lazy(Batch B) {
 // rank[v] (each with the first four bytes of its position), so 64 candidates are fetched with
 // one coalesced load, filtered with ballots
 // (same trigram, window LD:1365, dictionary rule Q10/LD:1394, "was inserted" from a bitmap of
-// the last 65536 positions in LDS), the nearest max_chain survivors are compared in
+// the last 40960 positions in LDS), the nearest max_chain survivors are compared in
 // parallel, and nice_length (LD:1389) cuts the list where the serial walk would have stopped.
 __device__ inline uint32_t gld4(const uint8_t *V, uint32_t off) {  // V is 16-byte aligned and padded
   const uint32_t *w = (const uint32_t *)(V + (off & ~3u));
   return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3);
 }
 
-__global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
-  __shared__ uint32_t s_ins[2048];  // bit (q & 65535): stream position q is in a hash chain (LD:1347)
+// The walk is bound by memory latency (two to three dependent round trips per token), so what
+// counts is how many streams a CU keeps in flight: a ring of 40960 positions (window + longest
+// match + slack; 5 KB) and 64 VGPRs let 8 wavefronts per SIMD be resident.
+constexpr uint32_t kInsWords = 1280;
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz_greedy(Batch B) {
+  __shared__ uint32_t s_ins[kInsWords];  // bit (q mod 40960): stream position q is in a hash chain (LD:1347)
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= B.count) return;
   const uint32_t n = stream_len(B, s), D = B.dlen;
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
   const uint32_t max_insert = (uint32_t)cfg.max_lazy;  // max_insert_length for these levels
   const uint32_t nblk = num_blocks(n);
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (uint32_t i = lane; i < 2048; i += kWave) s_ins[i] = 0;
+  for (uint32_t i = lane; i < kInsWords; i += kWave) s_ins[i] = 0;
   __syncthreads();
 
   for (uint32_t b = 0; b < nblk; b++) {
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
             first_brk = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
           }
           const uint32_t q = c - D;
-          const bool inserted = in_dict || ((s_ins[(q >> 5) & 2047] >> (q & 31)) & 1);
+          const bool inserted = in_dict || ((s_ins[(q >> 5) % kInsWords] >> (q & 31)) & 1);
           const bool cand = in_chain && lane < first_brk && inserted;
           const unsigned long long candm = __ballot(cand);
           const bool sel = cand && taken + (uint32_t)__popcll(candm & below) < max_chain;  // LD:1362
@@ -806,7 +810,8 @@ __global__ __launch_bounds__(kWave) void k_lz_greedy(Batch B) {
           const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
           const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
           const uint32_t val = interior_on ? mask : (lane == 0 ? 1u << (first & 31) : 0u);
-          s_ins[wi & 2047] = (s_ins[wi & 2047] & ~mask) | val;
+          const uint32_t slot = wi % kInsWords;
+          s_ins[slot] = (s_ins[slot] & ~mask) | val;
         }
       }
       __syncthreads();
