@@ -119,7 +119,7 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
       }
       S.leafs[rank] = (int16_t)i;
     }
-    nleaf += __popcll(__ballot(ci != 0));
+    nleaf += __popcll(ballot64(ci != 0));
   }
   __syncthreads();
   int max_nz = -1;
@@ -218,10 +218,10 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
       const int sy = base + (int)lane;
       const uint32_t len = sy < nsym ? S.len[sy] : 0;
       const bool active = len != 0;
-      unsigned long long mask = __ballot(active);
+      unsigned long long mask = ballot64(active);
 #pragma unroll
       for (int bit = 0; bit < 4; bit++) {
-        const unsigned long long bal = __ballot(active && ((len >> bit) & 1));
+        const unsigned long long bal = ballot64(active && ((len >> bit) & 1));
         mask &= ((len >> bit) & 1) ? bal : ~bal;
       }
       const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));

@@ -194,10 +194,10 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
     const int i = base + (int)lane;
     const uint32_t l = i < nsym ? lens[i] : 0;
     const bool active = l != 0;
-    unsigned long long mask = __ballot(active);
+    unsigned long long mask = ballot64(active);
 #pragma unroll
     for (int bit = 0; bit < 4; bit++) {
-      const unsigned long long bal = __ballot(active && ((l >> bit) & 1));
+      const unsigned long long bal = ballot64(active && ((l >> bit) & 1));
       mask &= ((l >> bit) & 1) ? bal : ~bal;
     }
     const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
@@ -426,7 +426,7 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     const bool err11 = is_len & (dist > my_pos + ext);  // LD:2406-2410
     const bool full = my_pos + out_len > cap;
     const bool exh = bit + tok_bits > lim;              // LD:2428
-    const unsigned long long stops = __ballot(is_tok & (hard | err11 | full | exh));
+    const unsigned long long stops = ballot64(is_tok & (hard | err11 | full | exh));
     const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
     const bool commit = is_tok & (lane < first);
     // ---- copies deferred by the previous round: their loads have had a whole round to land
@@ -444,12 +444,12 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     if (commit & is_lit) out[my_pos] = (uint8_t)sym;
     // ---- matches of this round
     const bool cm = commit & is_len;
-    unsigned long long mm = __ballot(cm);
+    unsigned long long mm = ballot64(cm);
     if (mm) {
       // a match whose source [dst-dist, dst-dist+len) lies wholly below `fenced` depends on
       // nothing in flight (this also excludes every self-overlapping match, dist < len)
       const bool near = cm & (my_pos + mlen > fenced + dist);
-      if (__ballot(near) == 0) {
+      if (ballot64(near) == 0) {
         // the first kPend of them: load now (one lane per byte), store in the next round
 #pragma unroll
         for (int q = 0; q < kPend; q++) {

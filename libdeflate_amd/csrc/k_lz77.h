@@ -180,13 +180,19 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
       for (int j = 0; j < kSortItems; j++) {
         const bool valid = e[j] != 0xFFFFFFFFu;
         // lanes of this wave holding the same digit (stable rank = lanes below me)
-        unsigned long long mask = __ballot(valid);
+        // (invalid lanes vote with digit 0; they are outside the initial mask, so a valid lane
+        // never counts them.  Written so that a bit costs v_bfe_i32 + v_cmp + two bit ops.)
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+        uint32_t mlo = (uint32_t)vm, mhi = (uint32_t)(vm >> 32);
 #pragma unroll
         for (int bit = 0; bit < 8; bit++) {
-          unsigned long long bal = __ballot(valid && ((d[j] >> bit) & 1));
-          mask &= ((d[j] >> bit) & 1) ? bal : ~bal;
+          const uint32_t m = (uint32_t)((int32_t)(d[j] << (31 - bit)) >> 31);  // all ones: my bit is set
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64((int32_t)m < 0);
+          mlo &= ~((uint32_t)bal ^ m);
+          mhi &= ~((uint32_t)(bal >> 32) ^ m);
         }
-        const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
         const uint32_t old = s_cnt[wave][d[j]];  // same digit in this wave's earlier sub-rounds
         lrank[j] = old + rank;
         __builtin_amdgcn_wave_barrier();
@@ -396,13 +402,13 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   // hop from candidate cb over link dn_ for the lanes in cond_; returns the lanes that go on
 #define LDH_HOP(cond_, dn_, go_)                                                                  \
   {                                                                                               \
-    const unsigned long long more_ = __ballot(d1 != 0);                                           \
+    const unsigned long long more_ = ballot64(d1 != 0);                                           \
     d1 -= (uint32_t)__builtin_amdgcn_inverse_ballot_w64(cond_);                                   \
     const uint32_t cn_ = cb - (dn_);                                                              \
-    go_ = (cond_) & more_ & __ballot((int32_t)cn_ >= lo);                                         \
+    go_ = (cond_) & more_ & ballot64((int32_t)cn_ >= lo);                                         \
     if (HAS_DICT) { /* dictionary side of V (Q10) */                                              \
       const uint32_t c_ = cn_ + wbase;                                                            \
-      const unsigned long long in_dict_ = __ballot(c_ < D), deep_ = __ballot(c_ + 2 < D);         \
+      const unsigned long long in_dict_ = ballot64(c_ < D), deep_ = ballot64(c_ + 2 < D);         \
       go_ &= ~(in_dict_ & deep_ & seed);                                                          \
       seed |= go_ & in_dict_ & ~deep_;                                                            \
     }                                                                                             \
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       }
       // a match of maxlen cannot be beaten (the walk has no side effects, so ending it early
       // leaves the result unchanged)
-      const unsigned long long open = __ballot((best < nice) & (best < maxlen));
+      const unsigned long long open = ballot64((best < nice) & (best < maxlen));
       unsigned long long go;
       LDH_HOP(cm & open, dn, go);
       act = (act & ~cm) | go;
@@ -477,10 +483,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
           }
         }
       }
-      const unsigned long long st = __ballot(started);
+      const unsigned long long st = ballot64(started);
       act |= st;
-      pend = (pend & ~idle) | __ballot(has_pos);
-      if (HAS_DICT) seed = (seed & ~idle) | (st & __ballot((cb + wbase < D) & !(cb + wbase + 2 < D)));
+      pend = (pend & ~idle) | ballot64(has_pos);
+      if (HAS_DICT) seed = (seed & ~idle) | (st & ballot64((cb + wbase < D) & !(cb + wbase + 2 < D)));
       if (base + nidle >= q1) exhausted = true;
       continue;
     }
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
 #pragma unroll
     for (uint32_t step = 0; step < steps_per_round; step++) {
       dn = lprev[cb];
-      pm = __ballot(lds_load2(lbytes, cb + off) == t2);
+      pm = ballot64(lds_load2(lbytes, cb + off) == t2);
       unsigned long long go;
       LDH_HOP(act & ~pm, dn, go);
       act = (act & pm) | go;
@@ -730,22 +736,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           const uint32_t c = ce.x, cw = ce.y;
           const bool ok = have && (cw & 0xFFFFFFu) == key && v - c <= kWindow;  // (another group's c may exceed v)
           // the chain is the run of ok lanes from lane 0
-          const unsigned long long notok = ~__ballot(ok);
+          const unsigned long long notok = ~ballot64(ok);
           const uint32_t first_bad = notok ? (uint32_t)__builtin_ctzll(notok) : 64u;
           const bool in_chain = lane < first_bad;
           const bool in_dict = c < D, deep = in_dict && c + 2 < D;
           unsigned long long seedm = 0;
           uint32_t first_brk = 64;
           if (D) {  // (uniform) the dictionary rule only exists with a dictionary
-            seedm = __ballot(in_chain && in_dict && !deep);
+            seedm = ballot64(in_chain && in_dict && !deep);
             const bool seen_before = seen_seed || (seedm & below) != 0;
-            const unsigned long long brk = __ballot(in_chain && deep && seen_before);  // LD:1394
+            const unsigned long long brk = ballot64(in_chain && deep && seen_before);  // LD:1394
             first_brk = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
           }
           const uint32_t q = c - D;
           const bool inserted = in_dict || ((s_ins[(q >> 5) % kInsWords] >> (q & 31)) & 1);
           const bool cand = in_chain && lane < first_brk && inserted;
-          const unsigned long long candm = __ballot(cand);
+          const unsigned long long candm = ballot64(cand);
           const bool sel = cand && taken + (uint32_t)__popcll(candm & below) < max_chain;  // LD:1362
           uint32_t L = 0;
           if (sel) {
@@ -763,9 +769,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             }
             if (L > maxlen) L = maxlen;
           }
-          const unsigned long long selm = __ballot(sel);
+          const unsigned long long selm = ballot64(sel);
           // nice_length: the walk stops at the nearest candidate that reaches it (LD:1389)
-          const unsigned long long nicem = __ballot(sel && L >= nice);
+          const unsigned long long nicem = ballot64(sel && L >= nice);
           const uint32_t first_nice = nicem ? (uint32_t)__builtin_ctzll(nicem) : 64u;
           // longest of the candidates up to there, nearest among equals (LD:1385)
           unsigned long long m = selm & (first_nice >= 63 ? ~0ull : ((2ull << first_nice) - 1ull));
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (__popcll(m) > 6) {  // narrow the set down bit by bit of L, most significant first
 #pragma unroll
               for (int bit = 8; bit >= 0; bit--) {
-                const unsigned long long t = m & __ballot((L >> bit) & 1);
+                const unsigned long long t = m & ballot64(((L >> bit) & 1) != 0);
                 if (t) m = t;
               }
             }

@@ -14,6 +14,10 @@
 namespace ldh {
 
 constexpr int kWave = 64;
+
+// HIP's __ballot takes an int: a predicate that is already a lane mask (an AND of two compares)
+// then goes through v_cndmask 0/1 + v_cmp to become a mask again.  The builtin takes the bool.
+__device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr uint32_t kWindow = 32768;   // LD:1365
 constexpr uint32_t kFirstBlock = 65535;  // LD:1795
 constexpr uint32_t kNextBlock = 32768;   // LD:1799
