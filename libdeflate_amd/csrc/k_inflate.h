@@ -460,7 +460,9 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
             const uint32_t d = __builtin_amdgcn_readlane(dist, j);
             const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
             if (len <= kWave) {
-              if (lane < len) {
+              if (d <= dst) {  // (uniform) the source lies in the output: no per-lane pointer select
+                if (lane < len) pval[q] = out[dst - d + lane];
+              } else if (lane < len) {
                 const uint32_t a = dst + lane;
                 pval[q] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
               }

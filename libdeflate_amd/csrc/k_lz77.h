@@ -477,6 +477,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
             bdist = 0;
             off = 0;
             started = d0 <= kWindow;  // chain empty (0xFFFF) / LD:1365
+            dn = lprev[cb];
             has_pos = true;
           } else {
             mout[my] = 0;
@@ -485,6 +486,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       }
       const unsigned long long st = ballot64(started);
       act |= st;
+      // the first candidate of a chain always passes the reject (best = 0: the bytes tested are
+      // the trigram's): hand it to the full compare at once instead of freezing the lane on it
+      // for a round
+      pm = st;
       pend = (pend & ~idle) | ballot64(has_pos);
       if (HAS_DICT) seed = (seed & ~idle) | (st & ballot64((cb + wbase < D) & !(cb + wbase + 2 < D)));
       if (base + nidle >= q1) exhausted = true;
