@@ -311,8 +311,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
 }
 
 // ------------------------------------------------------------------ k_match_lazy
-constexpr uint32_t kTile = 8192;
-constexpr int kMatchThreads = 1024;
+#ifndef LDH_MATCH_TILE
+#define LDH_MATCH_TILE 20480
+#endif
+#ifndef LDH_MATCH_THREADS
+#define LDH_MATCH_THREADS 1024
+#endif
+constexpr uint32_t kTile = LDH_MATCH_TILE;  // a multiple of 4096, at most 20480 (LDS; one deflate-block end per tile)
+constexpr int kMatchThreads = LDH_MATCH_THREADS;
 constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
 constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
 constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   }
   __syncthreads();
 
-  // a tile (8192 positions) straddles at most one deflate-block end
+  // a tile (at most 20480 positions) straddles at most one deflate-block end (they are 32768 apart)
   const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
   const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
   const uint32_t refill_idle = kRefillIdle;
@@ -455,34 +461,34 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&s_next, nidle);
       base = __builtin_amdgcn_readfirstlane(base);
+      // (one exec-masked straight-line body: nested branches here cost three sets of register
+      // copies per trip.  An idle lane's walk state is dead, so it is overwritten even when the
+      // lane gets no position or one that is not searched (LD:1349): that one keeps best = 0
+      // and is stored like any other result at the lane's next refill.)
       bool started = false, has_pos = false;
       if (idle & lane_bit) {
         if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
         const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
-        if (my < q1) {
-          const uint32_t p = my + 1;
-          const uint32_t be = p <= be_lo ? be_lo : be_hi;
-          if (p + 2 <= be) {  // LD:1349
-            q = my;
-            vb = my + D - wbase;
-            lo = (int32_t)vb - (int32_t)kWindow;
-            const uint32_t d0 = lprev[vb];
-            cb = vb - d0;
-            maxlen = be - p + 1;
-            if (maxlen > kMaxMatch) maxlen = kMaxMatch;
-            tw = lds_load8(lbytes, vb + 3);
-            t2 = lds_load2(lbytes, vb);
-            d1 = (uint32_t)cfg.max_chain - 1;  // Q3
-            best = 0;
-            bdist = 0;
-            off = 0;
-            started = d0 <= kWindow;  // chain empty (0xFFFF) / LD:1365
-            dn = lprev[cb];
-            has_pos = true;
-          } else {
-            mout[my] = 0;
-          }
-        }
+        has_pos = my < q1;
+        const uint32_t myc = has_pos ? my : q0;  // (keeps the LDS addresses below inside the staged range)
+        const uint32_t p = myc + 1;
+        const uint32_t be = p <= be_lo ? be_lo : be_hi;
+        q = myc;
+        vb = myc + D - wbase;
+        lo = (int32_t)vb - (int32_t)kWindow;
+        const uint32_t d0 = lprev[vb];
+        cb = vb - d0;
+        maxlen = be + 1 - p;
+        if (maxlen > kMaxMatch) maxlen = kMaxMatch;
+        tw = lds_load8(lbytes, vb + 3);
+        t2 = lds_load2(lbytes, vb);
+        d1 = (uint32_t)cfg.max_chain - 1;  // Q3
+        best = 0;
+        bdist = 0;
+        off = 0;
+        // LD:1349 (the last two positions of a block are not searched); chain empty (0xFFFF) / LD:1365
+        started = has_pos & (p + 2 <= be) & (d0 <= kWindow);
+        dn = lprev[cb];
       }
       const unsigned long long st = ballot64(started);
       act |= st;
