@@ -32,9 +32,12 @@ __device__ inline uint32_t trigram(const uint8_t *V, uint32_t v) {
 // LDS reads at any byte offset.  gfx950 accepts misaligned ds_read_u16 / _b32 / _b64 (the
 // compiler emits them for align-1 loads), but they are slow: with one misaligned ds_read_u16
 // per chain step k_match_lazy took 91 ms instead of 33.  So: aligned reads + alignbyte.
+// (the two bytes are joined by v_perm_b32, which the compiler does not see through: joined by
+// shift-and-or it may fuse the byte reads into exactly that misaligned ds_read_u16 -- it did
+// after a refactoring that changed nothing else, 27.7 -> 67 ms)
 __device__ inline uint32_t lds_load2(const uint32_t *w, uint32_t byteoff) {
   const uint8_t *b = (const uint8_t *)w + byteoff;
-  return (uint32_t)b[0] | ((uint32_t)b[1] << 8);
+  return __builtin_amdgcn_perm((uint32_t)b[1], (uint32_t)b[0], 0x0c0c0400u);
 }
 __device__ inline uint32_t lds_load4(const uint32_t *w, uint32_t byteoff) {
   uint32_t i = byteoff >> 2;
@@ -325,11 +328,8 @@ constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
 #ifndef LDH_MATCH_STEPS
 #define LDH_MATCH_STEPS 8
 #endif
-#ifndef LDH_REFILL_IDLE
-#define LDH_REFILL_IDLE 16
-#endif
+
 constexpr uint32_t kMatchSteps = LDH_MATCH_STEPS;  // chain steps between two looks at the long paths
-constexpr uint32_t kRefillIdle = LDH_REFILL_IDLE;  // lanes that must be idle before the wave fetches new positions
 
 // One lane works on one position at a time and walks its chain one candidate per loop
 // trip; lanes whose chain has ended take the next position of the tile from a workgroup
@@ -380,7 +380,6 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   // a tile (at most 20480 positions) straddles at most one deflate-block end (they are 32768 apart)
   const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
   const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
-  const uint32_t refill_idle = kRefillIdle;
 
   // Instruction issue bounds this loop (a wave64 VALU op holds its SIMD for 4 cycles, the
   // CU's one scalar unit issues one instruction per cycle), so the chain step is written to
@@ -421,8 +420,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     cb = __builtin_amdgcn_inverse_ballot_w64(go_) ? cn_ : cb;                                     \
   }
 
-  for (;;) {
-    // ---- batched full compare of the candidates that passed the quick reject
+  // ---- batched full compare of the candidates that passed the quick reject
+  auto compare = [&]() {
     const unsigned long long cm = act & pm;
     pm = 0;
     if (cm) {
@@ -430,13 +429,13 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
         const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
         uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
         if (x == 0) {
-          while (L < maxlen) {
-            const uint32_t y = lds_load4(lbytes, cb + L) ^ lds_load4(lbytes, vb + L);
+          while (L < maxlen) {  // (bytes are staged 280 past the tile's end: reading past maxlen is safe)
+            const uint64_t y = lds_load8(lbytes, cb + L) ^ lds_load8(lbytes, vb + L);
             if (y) {
-              L += __builtin_ctz(y) >> 3;
+              L += (uint32_t)__builtin_ctzll(y) >> 3;
               break;
             }
-            L += 4;
+            L += 8;
           }
         }
         if (L > maxlen) L = maxlen;
@@ -454,57 +453,61 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       LDH_HOP(cm & open, dn, go);
       act = (act & ~cm) | go;
     }
-    // ---- refill idle lanes
-    const unsigned long long idle = ~act;
-    const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (!exhausted && (nidle >= refill_idle)) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&s_next, nidle);
-      base = __builtin_amdgcn_readfirstlane(base);
-      // (one exec-masked straight-line body: nested branches here cost three sets of register
-      // copies per trip.  An idle lane's walk state is dead, so it is overwritten even when the
-      // lane gets no position or one that is not searched (LD:1349): that one keeps best = 0
-      // and is stored like any other result at the lane's next refill.)
-      bool started = false, has_pos = false;
-      if (idle & lane_bit) {
-        if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
-        const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
-        has_pos = my < q1;
-        const uint32_t myc = has_pos ? my : q0;  // (keeps the LDS addresses below inside the staged range)
-        const uint32_t p = myc + 1;
-        const uint32_t be = p <= be_lo ? be_lo : be_hi;
-        q = myc;
-        vb = myc + D - wbase;
-        lo = (int32_t)vb - (int32_t)kWindow;
-        const uint32_t d0 = lprev[vb];
-        cb = vb - d0;
-        maxlen = be + 1 - p;
-        if (maxlen > kMaxMatch) maxlen = kMaxMatch;
-        tw = lds_load8(lbytes, vb + 3);
-        t2 = lds_load2(lbytes, vb);
-        d1 = (uint32_t)cfg.max_chain - 1;  // Q3
-        best = 0;
-        bdist = 0;
-        off = 0;
-        // LD:1349 (the last two positions of a block are not searched); chain empty (0xFFFF) / LD:1365
-        started = has_pos & (p + 2 <= be) & (d0 <= kWindow);
-        dn = lprev[cb];
-      }
-      const unsigned long long st = ballot64(started);
-      act |= st;
-      // the first candidate of a chain always passes the reject (best = 0: the bytes tested are
-      // the trigram's): hand it to the full compare at once instead of freezing the lane on it
-      // for a round
-      pm = st;
-      pend = (pend & ~idle) | ballot64(has_pos);
-      if (HAS_DICT) seed = (seed & ~idle) | (st & ballot64((cb + wbase < D) & !(cb + wbase + 2 < D)));
-      if (base + nidle >= q1) exhausted = true;
-      continue;
-    }
-    if (nidle == 64) break;
-    // ---- chain steps: one LDS round trip each (link of the candidate + its reject bytes).
-    // A candidate can only beat `best` if it also matches at offsets best-1 and best (the
-    // trigram makes offsets 0..2 equal): two bytes reject nearly every candidate.
+  };
+  // ---- refill idle lanes
+  auto refill = [&](unsigned long long idle, uint32_t nidle) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&s_next, nidle);
+    base = __builtin_amdgcn_readfirstlane(base);
+    // (no divergent branch around the new walk state: every lane computes one -- lanes that
+    // are not idle from a clamped position -- and idle lanes select it.  The compiler turns a
+    // branch here into a copy of all twelve state registers on both sides of it, per trip.  An
+    // idle lane's walk state is dead, so it is overwritten even when the lane gets no position
+    // or one that is not searched (LD:1349): that one keeps best = 0 and is stored like any
+    // other result at the lane's next refill.)
+    const bool mine = (idle & lane_bit) != 0;
+    if (mine && (pend & lane_bit)) mout[q] = best ? ((best << 16) | bdist) : 0u;
+    const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
+    const bool has_pos = mine & (my < q1);
+    const uint32_t myc = has_pos ? my : q0;  // (keeps the LDS addresses below inside the staged range)
+    const uint32_t p = myc + 1;
+    const uint32_t be = p <= be_lo ? be_lo : be_hi;
+    const uint32_t vbn = myc + D - wbase;
+    const uint32_t d0 = lprev[vbn];
+    const uint32_t cbn = vbn - d0;
+    const uint32_t mln = be + 1 - p;
+    const uint64_t twn = lds_load8(lbytes, vbn + 3);
+    const uint32_t t2n = lds_load2(lbytes, vbn);
+    const uint32_t dnn = lprev[cbn];
+    q = mine ? myc : q;
+    vb = mine ? vbn : vb;
+    lo = mine ? (int32_t)vbn - (int32_t)kWindow : lo;
+    cb = mine ? cbn : cb;
+    maxlen = mine ? (mln > kMaxMatch ? kMaxMatch : mln) : maxlen;
+    tw = mine ? twn : tw;
+    t2 = mine ? t2n : t2;
+    d1 = mine ? (uint32_t)cfg.max_chain - 1 : d1;  // Q3
+    best = mine ? 0u : best;
+    bdist = mine ? 0u : bdist;
+    off = mine ? 0u : off;
+    dn = mine ? dnn : dn;
+    // LD:1349 (the last two positions of a block are not searched); chain empty (0xFFFF) / LD:1365
+    const bool started = has_pos & (p + 2 <= be) & (d0 <= kWindow);
+    const unsigned long long st = ballot64(started);
+    act |= st;
+    // the first candidate of a chain always passes the reject (best = 0: the bytes tested are
+    // the trigram's): hand it to the full compare at once instead of freezing the lane on it
+    // for a round
+    pm |= st;
+    pend = (pend & ~idle) | ballot64(has_pos);
+    if (HAS_DICT) seed = (seed & ~idle) | (st & ballot64((cb + wbase < D) & !(cb + wbase + 2 < D)));
+    if (base + nidle >= q1) exhausted = true;
+  };
+
+  // ---- chain steps: one LDS round trip each (link of the candidate + its reject bytes).
+  // A candidate can only beat `best` if it also matches at offsets best-1 and best (the
+  // trigram makes offsets 0..2 equal): two bytes reject nearly every candidate.
+  auto steps = [&]() {
 #pragma unroll
     for (uint32_t step = 0; step < steps_per_round; step++) {
       dn = lprev[cb];
@@ -513,6 +516,21 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       LDH_HOP(act & ~pm, dn, go);
       act = (act & pm) | go;
     }
+  };
+
+  // While the tile has positions left every round refills whatever is idle (about 17 lanes
+  // finish per round, so a threshold saved little and its branch cost a register shuffle on
+  // both sides); then the walks in flight drain.
+  while (!exhausted) {
+    const unsigned long long idle = ~act;
+    refill(idle, (uint32_t)__popcll(idle));
+    compare();
+    steps();
+  }
+  for (;;) {
+    compare();
+    if (!act) break;
+    steps();
   }
 #undef LDH_HOP
   if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
