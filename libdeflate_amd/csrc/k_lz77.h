@@ -235,6 +235,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     __syncthreads();
   }
 
+#ifdef LDH_SORT_STOP
+  if (LDH_SORT_STOP == 4) return;
+#endif
   if (B.want_rank) {
     // greedy levels walk the sorted array itself (k_lz_greedy): no links, only the inverse permutation
     for (uint32_t r = tid; r < nv; r += kSortThreads) rank[SRT(r)] = r;
@@ -404,11 +407,18 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   uint64_t tw = 0;
   const uint64_t lane_bit = 1ull << lane;
 
+  // x -= 1 in the lanes of a wave-uniform mask: one subtract-with-borrow whose borrow-in is the
+  // mask (the compiler's own choice is a select of 0 / 1 and a subtract)
+#define LDH_DEC_MASKED(x_, m_)                                                                    \
+  {                                                                                               \
+    unsigned long long bo_;                                                                       \
+    asm("v_subbrev_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(x_), "=s"(bo_) : "s"(m_));                \
+  }
   // hop from candidate cb over link dn_ for the lanes in cond_; returns the lanes that go on
 #define LDH_HOP(cond_, dn_, go_)                                                                  \
   {                                                                                               \
     const unsigned long long more_ = ballot64(d1 != 0);                                           \
-    d1 -= (uint32_t)__builtin_amdgcn_inverse_ballot_w64(cond_);                                   \
+    LDH_DEC_MASKED(d1, cond_);                                                                    \
     const uint32_t cn_ = cb - (dn_);                                                              \
     go_ = (cond_) & more_ & ballot64((int32_t)cn_ >= lo);                                         \
     if (HAS_DICT) { /* dictionary side of V (Q10) */                                              \
@@ -459,12 +469,12 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&s_next, nidle);
     base = __builtin_amdgcn_readfirstlane(base);
-    // (no divergent branch around the new walk state: every lane computes one -- lanes that
-    // are not idle from a clamped position -- and idle lanes select it.  The compiler turns a
-    // branch here into a copy of all twelve state registers on both sides of it, per trip.  An
-    // idle lane's walk state is dead, so it is overwritten even when the lane gets no position
-    // or one that is not searched (LD:1349): that one keeps best = 0 and is stored like any
-    // other result at the lane's next refill.)
+    // (The new walk state is computed by every lane -- lanes that are not idle from a clamped
+    // position -- and taken over by the idle ones in one exec-masked block of plain moves: with
+    // the loads inside a branch the compiler copies all twelve state registers on both sides of
+    // it, per trip.  An idle lane's walk state is dead, so it is overwritten even when the lane
+    // gets no position or one that is not searched (LD:1349): that one keeps best = 0 and is
+    // stored like any other result at the lane's next refill.)
     const bool mine = (idle & lane_bit) != 0;
     if (mine && (pend & lane_bit)) mout[q] = best ? ((best << 16) | bdist) : 0u;
     const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
@@ -479,18 +489,20 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     const uint64_t twn = lds_load8(lbytes, vbn + 3);
     const uint32_t t2n = lds_load2(lbytes, vbn);
     const uint32_t dnn = lprev[cbn];
-    q = mine ? myc : q;
-    vb = mine ? vbn : vb;
-    lo = mine ? (int32_t)vbn - (int32_t)kWindow : lo;
-    cb = mine ? cbn : cb;
-    maxlen = mine ? (mln > kMaxMatch ? kMaxMatch : mln) : maxlen;
-    tw = mine ? twn : tw;
-    t2 = mine ? t2n : t2;
-    d1 = mine ? (uint32_t)cfg.max_chain - 1 : d1;  // Q3
-    best = mine ? 0u : best;
-    bdist = mine ? 0u : bdist;
-    off = mine ? 0u : off;
-    dn = mine ? dnn : dn;
+    if (mine) {
+      q = myc;
+      vb = vbn;
+      lo = (int32_t)vbn - (int32_t)kWindow;
+      cb = cbn;
+      maxlen = mln > kMaxMatch ? kMaxMatch : mln;
+      tw = twn;
+      t2 = t2n;
+      d1 = (uint32_t)cfg.max_chain - 1;  // Q3
+      best = 0u;
+      bdist = 0u;
+      off = 0u;
+      dn = dnn;
+    }
     // LD:1349 (the last two positions of a block are not searched); chain empty (0xFFFF) / LD:1365
     const bool started = has_pos & (p + 2 <= be) & (d0 <= kWindow);
     const unsigned long long st = ballot64(started);
@@ -533,6 +545,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     steps();
   }
 #undef LDH_HOP
+#undef LDH_DEC_MASKED
   if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
 }
 
