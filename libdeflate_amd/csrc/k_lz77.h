@@ -81,10 +81,15 @@ __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *o
   __syncthreads();
 }
 
-// V_LDS: the whole virtual buffer also lives in LDS (streams up to kSortLdsMaxV bytes), so
-// the per-element key fetches of passes 1-2 and the trigram compares of the link pass are
-// LDS byte reads instead of fully divergent global loads (which bound the first version).
+// V_LDS: the bytes being sorted also live in LDS (up to kSortLdsMaxV of them), so the
+// per-element key fetches of passes 1-2 and the trigram compares of the link pass are LDS
+// byte reads instead of fully divergent global loads (which bound the first version).
 constexpr uint32_t kSortLdsMaxV = 131072 + 64;
+// A virtual buffer too long for that (a 128 KiB stream behind a 32 KiB dictionary; SURVEY 8.f N4:
+// one long stream) is sorted in segments, one workgroup each: chains never reach back more than
+// 32768 positions (LD:1365), so the links of positions [g*kSegOut, (g+1)*kSegOut) need only the
+// positions from g*kSegOut - 32768 on.  A segment sorts at most 131072 positions.
+constexpr uint32_t kSegOut = 131072 - kWindow;
 
 template <bool V_LDS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
@@ -96,14 +101,21 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   __shared__ uint16_t s_pre[kSortWaves][256];
   __shared__ uint32_t s_tot[4];
 
-  const uint32_t s = blockIdx.x;
+  const uint32_t s = blockIdx.x / B.segs, seg = blockIdx.x % B.segs;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t n = stream_len(B, s), D = B.dlen, nv = D + n;
-  uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint32_t n = stream_len(B, s), D = B.dlen, nv_all = D + n;
+  // this workgroup sorts V positions [lo, hi) and produces the links of [out0, hi); all element
+  // indices below are relative to lo.  One segment: lo = out0 = 0, hi = nv_all.
+  const uint32_t out0 = B.segs > 1 ? seg * kSegOut : 0u;
+  if (seg > 0 && out0 >= nv_all) return;
+  const uint32_t hi = (B.segs > 1 && out0 + kSegOut < nv_all) ? out0 + kSegOut : nv_all;
+  const uint32_t lo = out0 > kWindow ? out0 - kWindow : 0u;
+  const uint32_t nv = hi - lo, keep0 = out0 - lo;
+  uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad) + lo;
   const uint8_t *in = B.in + B.in_off[s];
-  uint32_t *bufA = B.bufA + (size_t)s * B.nvp;
-  uint32_t *bufB = B.bufB + (size_t)s * B.nvp;
-  uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+  uint32_t *bufA = B.sortA + (size_t)blockIdx.x * B.sort_stride;
+  uint32_t *bufB = B.sortB + (size_t)blockIdx.x * B.sort_stride;
+  uint16_t *prevd = B.prevd + (size_t)s * B.nvp + lo;
   // where the sorted array ends up; greedy levels also get its inverse (rank of a position)
   // (greedy levels: entries of the final array carry the first four bytes of their position too)
   uint2 *srt2 = B.want_rank ? (uint2 *)B.bufC + (size_t)s * B.nvp : nullptr;
@@ -115,21 +127,21 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
   for (uint32_t i = tid; i < kSortWaves * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
 
-  // V = dict ++ input ++ zeros, written as dwords (V is 16-byte aligned)
-  const uint32_t total = (nv + kVPad) & ~3u;  // nv + kVPad <= nvp + kVPad
+  // V = dict ++ input ++ zeros, written as dwords (V and lo are 4-byte aligned).  The kVPad bytes
+  // after the segment are the next segment's first bytes, or the zeros after the stream's end.
+  // Global V is written from out0 on (what lies before is another segment's to write).
+  const uint32_t total = (nv + kVPad) & ~3u;  // lo + nv + kVPad <= nvp + kVPad
   for (uint32_t w = tid * 4; w < total; w += kSortThreads * 4) {
     uint32_t word = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      uint32_t i = w + k;
+      const uint32_t i = w + k, gi = lo + i;
       uint32_t byte = 0;
-      if (i < nv) {
-        byte = i < D ? B.dict[i] : in[i - D];
-        atomicAdd(&s_hist[byte], 1u);
-      }
+      if (gi < nv_all) byte = gi < D ? B.dict[gi] : in[gi - D];
+      if (i < nv) atomicAdd(&s_hist[byte], 1u);
       word |= byte << (8 * k);
     }
-    *(uint32_t *)(V + w) = word;
+    if (w >= keep0) *(uint32_t *)(V + w) = word;
     if (V_LDS) *(uint32_t *)(ldsV + w) = word;
   }
   __syncthreads();
@@ -145,13 +157,13 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     const uint32_t shift = 2 - pass;  // digit of v is V[v + shift]
     const uint32_t *src = pass == 1 ? bufA : bufB;
     uint32_t *dst = pass == 1 ? bufB : bufA;
-    {  // bin bases: histogram of V[shift .. shift+nv-1] (zero padded), exclusive scan
+    {  // bin bases: histogram of V[shift .. shift+nv-1], exclusive scan
       uint32_t cnt = 0;
       if (tid < 256) {
-        const uint32_t m = shift < nv ? shift : nv;
+        // s_hist counts V[0 .. nv-1]: take out what lies before `shift`, add what lies beyond nv
+        const uint32_t m = shift < nv ? shift : nv, beyond = nv > shift ? nv : shift;
         cnt = s_hist[tid];
-        for (uint32_t j = 0; j < m; j++) cnt -= (VBYTE(j) == tid);
-        if (tid == 0) cnt += m;
+        for (uint32_t j = 0; j < m; j++) cnt += (VBYTE(beyond + j) == tid) - (VBYTE(j) == tid);
       }
       scan256_exclusive(cnt, tid, s_base, s_tot);
     }
@@ -240,6 +252,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
 #endif
   if (B.want_rank) {
     // greedy levels walk the sorted array itself (k_lz_greedy): no links, only the inverse permutation
+    // (never segmented: the host keeps segs = 1 for these levels)
     for (uint32_t r = tid; r < nv; r += kSortThreads) rank[SRT(r)] = r;
     return;
   }
@@ -275,8 +288,8 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
     }
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
-    const uint32_t H = (((B.nvp + kVPad + 15) & ~15u) / 2) & ~1u;  // positions whose links fit V's LDS (>= 24, even)
-    for (uint32_t h0 = 0; h0 < nv; h0 += H) {
+    const uint32_t H = (B.sort_lds / 2) & ~1u;  // positions whose links fit V's LDS (>= 24, even)
+    for (uint32_t h0 = keep0; h0 < nv; h0 += H) {  // (positions before out0 are only predecessors here)
       for (uint32_t r0 = tid; r0 < nv; r0 += kSortThreads * kLinkItems) {
         uint32_t v[kLinkItems], l[kLinkItems];
 #pragma unroll
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
           if (v[j] != 0xFFFFFFFFu && v[j] - h0 < H) l16[v[j] - h0] = (uint16_t)l[j];
       }
       __syncthreads();
-      const uint32_t cnt = nv - h0 < H ? nv - h0 : H;  // prevd rows are 4-byte aligned (nvp % 16 == 0)
+      const uint32_t cnt = nv - h0 < H ? nv - h0 : H;  // prevd rows, lo, keep0 and H are even: 4-byte aligned
       const uint32_t *src32 = (const uint32_t *)l16;
       uint32_t *dst32 = (uint32_t *)(prevd + h0);
       for (uint32_t i = tid; i < (cnt + 1) / 2; i += kSortThreads) dst32[i] = src32[i];

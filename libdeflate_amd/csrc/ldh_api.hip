@@ -45,7 +45,7 @@ struct DevBuf {
   size_t cap = 0;
 };
 // workspace (grow-only)
-DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_bufC, g_blocks, g_adler, g_misc32a, g_misc32b;
+DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_bufC, g_sortA, g_sortB, g_blocks, g_adler, g_misc32a, g_misc32b;
 // staging for the host-pointer entry points
 DevBuf g_h_in, g_h_off, g_h_out, g_h_len, g_h_aux8, g_h_aux32a, g_h_aux32b, g_codec_tmp;
 
@@ -197,7 +197,13 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   const uint32_t max_blocks = num_blocks((uint32_t)max_in_len);
 
   const bool greedy = need_lz && !level_cfg(level).lazy;  // levels 1-3
-  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 16ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
+  // k_sort_links keeps what it sorts in LDS; a longer V (a dictionary in front of 128 KiB, or one
+  // long stream) is sorted in segments of at most 131072 positions with ping-pong arrays of their own
+  const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
+  const uint32_t segs = (!sort_in_lds && need_lz && !greedy) ? (uint32_t)((vd + max_in_len + kSegOut - 1) / kSegOut) : 1u;
+  const uint32_t seg_stride = kSegOut + kWindow;
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 16ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4 +
+                            (segs > 1 ? 8ull * segs * seg_stride : 0ull);
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
 
@@ -209,6 +215,10 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     if (int rc = ensure(g_bufC, chunk * 8ull * nvp + 64)) return rc;
   if (int rc = ensure(g_blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
   if (int rc = ensure(g_adler, chunk * 4 + 64)) return rc;
+  if (segs > 1) {
+    if (int rc = ensure(g_sortA, chunk * 4ull * segs * seg_stride + 64)) return rc;
+    if (int rc = ensure(g_sortB, chunk * 4ull * segs * seg_stride + 64)) return rc;
+  }
 
   if (!g_attr_done) {
     HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -241,6 +251,11 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.bufB = (uint32_t *)g_bufB.p;
     B.bufC = greedy ? (uint32_t *)g_bufC.p : nullptr;
     B.want_rank = greedy ? 1u : 0u;
+    B.segs = segs;
+    B.sortA = segs > 1 ? (uint32_t *)g_sortA.p : B.bufA;
+    B.sortB = segs > 1 ? (uint32_t *)g_sortB.p : B.bufB;
+    B.sort_stride = segs > 1 ? seg_stride : nvp;
+    B.sort_lds = segs > 1 ? ((seg_stride + kVPad + 15) & ~15u) : (sort_in_lds ? ((nvp + kVPad + 15) & ~15u) : 0u);
     B.need_lz = need_lz ? 1u : 0u;
     B.blocks = (BlockInfo *)g_blocks.p;
     B.adler = (uint32_t *)g_adler.p;
@@ -258,12 +273,16 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
       HIPCHK(hipMemsetAsync(g_bufA.p, 0xA5, g_bufA.cap, g_stream));
       HIPCHK(hipMemsetAsync(g_bufB.p, 0xA5, g_bufB.cap, g_stream));
       if (greedy) HIPCHK(hipMemsetAsync(g_bufC.p, 0xA5, g_bufC.cap, g_stream));
+      if (segs > 1) {
+        HIPCHK(hipMemsetAsync(g_sortA.p, 0xA5, g_sortA.cap, g_stream));
+        HIPCHK(hipMemsetAsync(g_sortB.p, 0xA5, g_sortB.cap, g_stream));
+      }
       HIPCHK(hipMemsetAsync(g_blocks.p, 0xA5, g_blocks.cap, g_stream));
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
     }
     // V (and, for the match search, the trigram chains)
-    if ((size_t)nvp + kVPad <= kSortLdsMaxV)
-      LAUNCH("k_sort_links", k_sort_links<true>, c, kSortThreads, (nvp + kVPad + 15) & ~15u, B);
+    if (B.sort_lds)
+      LAUNCH("k_sort_links", k_sort_links<true>, c * segs, kSortThreads, B.sort_lds, B);
     else
       LAUNCH("k_sort_links", k_sort_links<false>, c, kSortThreads, 0, B);
     if (level != 0) {
@@ -491,7 +510,7 @@ void ldh_shutdown(void) {
   if (g_device < 0) return;
   hipDeviceSynchronize();
   pipeline_free();
-  for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_bufC, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
+  for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_bufC, &g_sortA, &g_sortB, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
                     &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b, &g_codec_tmp}) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;

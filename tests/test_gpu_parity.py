@@ -195,6 +195,27 @@ def test_large_streams(LD, B):
             assert g == o_compress(s, zlib=True, level=level, dict=dct), (level, len(s))
 
 
+def test_segmented_sort(LD, B):
+    # lazy levels sort a virtual buffer that does not fit LDS in segments of 131072 positions (98304 of them new):
+    # BASELINE configs[3] shape (128 KiB streams behind the 32 KiB dictionary), one long stream next to
+    # short ones (segments past a stream's end), and lengths around the segment edges
+    from libdeflate_amd import synth
+    dct = golden("dictionary32768.txt")
+    d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
+    text = [r.tobytes() for r in synth.text_streams(3, 131072)]
+    text += [dct[5000:9000] + text[0][:70000], text[1][:98304 - 32768 + 1], b""]
+    for level in (5, 8):
+        for s, g in zip(text, B.compress_batch(text, fmt=1, level=level, dictionary=d)):
+            assert g == o_compress(s, zlib=True, level=level, dict=dct), (level, len(s))
+    long_one = b"".join(r.tobytes() for r in synth.text_streams(20, 131072))[:2500001]
+    edge = [long_one, long_one[:98304], long_one[:98305], long_one[:131073], long_one[:196608], long_one[:196609], b"q"]
+    got = B.compress_batch(edge, level=5)
+    for s, g in zip(edge, got):
+        assert g == o_compress(s, level=5), len(s)
+    back = B.decompress_batch([c for c, _ in got], max_out=len(long_one))
+    assert [x for x, _ in back] == edge
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 15, 16, 17, 47, 48, 63, 64, 65, 80, 127, 128, 129])
 def test_tiny_batches(B, n):
     # a batch whose longest stream is tiny sizes every per-stream buffer (and every loop bound derived from it) small
