@@ -51,7 +51,11 @@ __device__ inline uint64_t lds_load8(const uint32_t *w, uint32_t byteoff) {
 
 // ------------------------------------------------------------------ k_sort_links
 constexpr int kSortThreads = 1024;
-constexpr int kSortWaves = kSortThreads / kWave;
+constexpr int kSortThreadsNarrow = 256;
+#ifndef LDH_SORT_NARROW_MAX
+#define LDH_SORT_NARROW_MAX 16384
+#endif
+constexpr uint32_t kSortNarrowMaxLds = LDH_SORT_NARROW_MAX;  // streams up to about this long take the narrow version
 #ifndef LDH_SORT_ITEMS
 #define LDH_SORT_ITEMS 8
 #endif
@@ -91,8 +95,11 @@ constexpr uint32_t kSortLdsMaxV = 131072 + 64;
 // positions from g*kSegOut - 32768 on.  A segment sorts at most 131072 positions.
 constexpr uint32_t kSegOut = 131072 - kWindow;
 
-template <bool V_LDS>
-__global__ __launch_bounds__(kSortThreads) void k_sort_links(Batch B) {
+// THREADS: 1024, or 256 for batches of short streams (a 4 KiB stream is half a tile of the wide
+// version, and four times as many workgroups fit a CU)
+template <bool V_LDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
+  constexpr int kSortThreads = THREADS, kSortWaves = THREADS / kWave;
   extern __shared__ uint8_t ldsV[];
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_base[256];

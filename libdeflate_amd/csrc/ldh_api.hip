@@ -221,7 +221,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   }
 
   if (!g_attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true, kSortThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(kSortLdsMaxV)));
     HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)kMatchLdsBytes));
@@ -281,10 +281,12 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
     }
     // V (and, for the match search, the trigram chains)
-    if (B.sort_lds)
-      LAUNCH("k_sort_links", k_sort_links<true>, c * segs, kSortThreads, B.sort_lds, B);
+    if (B.sort_lds && B.sort_lds <= kSortNarrowMaxLds)
+      LAUNCH("k_sort_links", (k_sort_links<true, kSortThreadsNarrow>), c, kSortThreadsNarrow, B.sort_lds, B);
+    else if (B.sort_lds)
+      LAUNCH("k_sort_links", (k_sort_links<true, kSortThreads>), c * segs, kSortThreads, B.sort_lds, B);
     else
-      LAUNCH("k_sort_links", k_sort_links<false>, c, kSortThreads, 0, B);
+      LAUNCH("k_sort_links", (k_sort_links<false, kSortThreads>), c, kSortThreads, 0, B);
     if (level != 0) {
       if (strategy == LDH_STRATEGY_HUFFMAN_ONLY) {
         LAUNCH("k_tokens_literal", k_tokens_literal, c, 256, 0, B);

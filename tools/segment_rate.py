@@ -24,6 +24,7 @@ def run(tag, data, off, L, fmt, level, dictionary, check_inflate=True):
     back_len = torch.zeros(S, dtype=torch.int32, device=dev)
     left = torch.zeros(S, dtype=torch.int32, device=dev)
     status = torch.zeros(S, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the library runs on a stream of its own: torch's fills and copies must have landed
     for rep in range(2):
         B.profile(True)
         B.profile_reset()
