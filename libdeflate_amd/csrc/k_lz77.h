@@ -244,6 +244,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
             const uint32_t w4 = V_LDS ? lds_load4((const uint32_t *)ldsV, e[j])
                                       : VBYTE(e[j]) | (VBYTE(e[j] + 1) << 8) | (VBYTE(e[j] + 2) << 16) | (VBYTE(e[j] + 3) << 24);
             srt2[at] = make_uint2(e[j], w4);
+            if (V_LDS) dst[at] = e[j];  // (the compact copy the un-sort below reads)
           } else {
             dst[at] = e[j];
           }
@@ -260,7 +261,33 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
   if (B.want_rank) {
     // greedy levels walk the sorted array itself (k_lz_greedy): no links, only the inverse permutation
     // (never segmented: the host keeps segs = 1 for these levels)
-    for (uint32_t r = tid; r < nv; r += kSortThreads) rank[SRT(r)] = r;
+    if (V_LDS) {
+      // like the links below: scattering 4-byte ranks by position straight to memory took longer than
+      // the three sort passes together; V's LDS (free now) takes the ranks of a quarter of the positions
+      // at a time and they are copied out in order
+      uint32_t *l32 = (uint32_t *)ldsV;
+      const uint32_t H4 = (B.sort_lds / 4) & ~3u;
+      constexpr uint32_t kItems = LDH_LINK_ITEMS;
+      for (uint32_t h0 = 0; h0 < nv; h0 += H4) {
+        for (uint32_t r0 = tid; r0 < nv; r0 += kSortThreads * kItems) {
+          uint32_t v[kItems];
+#pragma unroll
+          for (uint32_t j = 0; j < kItems; j++) {
+            const uint32_t r = r0 + j * kSortThreads;
+            v[j] = r < nv ? bufA[r] : 0xFFFFFFFFu;
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < kItems; j++)
+            if (v[j] != 0xFFFFFFFFu && v[j] - h0 < H4) l32[v[j] - h0] = r0 + j * kSortThreads;
+        }
+        __syncthreads();
+        const uint32_t cnt = nv - h0 < H4 ? nv - h0 : H4;
+        for (uint32_t i = tid; i < cnt; i += kSortThreads) rank[h0 + i] = l32[i];
+        __syncthreads();
+      }
+    } else {
+      for (uint32_t r = tid; r < nv; r += kSortThreads) rank[SRT(r)] = r;
+    }
     return;
   }
   // links: neighbours in sorted order that share the trigram
