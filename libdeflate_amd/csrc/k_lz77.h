@@ -379,12 +379,19 @@ constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
 #define LDH_MATCH_STEPS 8
 #endif
 
+#ifndef LDH_REFILL_MIN_DEEP
+#define LDH_REFILL_MIN_DEEP 12
+#endif
+constexpr int kRefillMinDeep = LDH_REFILL_MIN_DEEP;  // REFILL_MIN of k_match_lazy for levels 7-9
 constexpr uint32_t kMatchSteps = LDH_MATCH_STEPS;  // chain steps between two looks at the long paths
 
 // One lane works on one position at a time and walks its chain one candidate per loop
 // trip; lanes whose chain has ended take the next position of the tile from a workgroup
 // counter (chains are 0..max_chain long, so a static position->lane map idles most lanes).
-template <bool HAS_DICT>
+// REFILL_MIN: idle lanes a wave waits for before it fetches new positions.  1 (levels 4-6): every
+// round, with no branch around the refill.  At max_chain 256 and more a round ends only about four
+// walks, and running the refill for them every round costs more than letting them wait.
+template <bool HAS_DICT, int REFILL_MIN>
 __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t tiles_per_stream) {
   extern __shared__ uint32_t smem[];
   uint32_t *lbytes = smem;                                 // kLdsByteCap bytes
@@ -582,7 +589,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   // both sides); then the walks in flight drain.
   while (!exhausted) {
     const unsigned long long idle = ~act;
-    refill(idle, (uint32_t)__popcll(idle));
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    if (REFILL_MIN <= 1 || nidle >= (uint32_t)REFILL_MIN) refill(idle, nidle);
     compare();
     steps();
   }

@@ -223,10 +223,9 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   if (!g_attr_done) {
     HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true, kSortThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(kSortLdsMaxV)));
-    HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)kMatchLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void *)k_match_lazy<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)kMatchLdsBytes));
+    for (const void *f : {(const void *)k_match_lazy<false, 1>, (const void *)k_match_lazy<true, 1>,
+                          (const void *)k_match_lazy<false, kRefillMinDeep>, (const void *)k_match_lazy<true, kRefillMinDeep>})
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     g_attr_done = true;
   }
 
@@ -292,8 +291,11 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
         LAUNCH("k_tokens_literal", k_tokens_literal, c, 256, 0, B);
       } else if (level_cfg(level).lazy) {
         const uint32_t tiles = (uint32_t)((max_in_len + kTile - 1) / kTile);
-        if (tiles && vd) LAUNCH("k_match_lazy", k_match_lazy<true>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
-        if (tiles && !vd) LAUNCH("k_match_lazy", k_match_lazy<false>, c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        const bool deep = level_cfg(level).max_chain >= 256;
+        if (tiles && vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, 1>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        if (tiles && !vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, 1>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        if (tiles && vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        if (tiles && !vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
         LAUNCH("k_parse_lazy", k_parse_lazy, c * max_blocks, kParseThreads, 0, B);
       } else {
         LAUNCH("k_lz_greedy", k_lz_greedy, c, kWave, 0, B);
