@@ -518,6 +518,7 @@ __device__ inline void pack_round(Packer &P, const uint64_t *val, const uint32_t
 __global__ __launch_bounds__(kPackThreads) void k_bitpack(Batch B) {
   __shared__ uint32_t s_img[kPackWords];
   __shared__ uint32_t s_scan[kPackThreads / 64 + 1];
+  __shared__ uint32_t s_lc[286], s_dc[30];
   const uint32_t s = blockIdx.x / B.max_blocks, b = blockIdx.x % B.max_blocks;
   const uint32_t n = stream_len(B, s);
   const uint32_t nblk = num_blocks(n);
@@ -542,6 +543,12 @@ __global__ __launch_bounds__(kPackThreads) void k_bitpack(Batch B) {
   P.block_first_word = P.first_word;
   P.block_first_partial = true;  // the block's first word may be shared; k_plan zeroed it
   for (uint32_t i = tid; i < (uint32_t)kPackWords; i += kPackThreads) s_img[i] = 0;
+  // the block's codes (code | length << 16) go to LDS once: per token they were two to four
+  // gathers from BlockInfo in global memory
+  if (type == 2) {
+    for (uint32_t i = tid; i < 286; i += kPackThreads) s_lc[i] = (uint32_t)bi->l_code[i] | ((uint32_t)bi->l_len[i] << 16);
+    if (tid < 30) s_dc[tid] = (uint32_t)bi->d_code[tid] | ((uint32_t)bi->d_len[tid] << 16);
+  }
   __syncthreads();
 
   uint64_t val[kPackItems];
@@ -648,10 +655,11 @@ __global__ __launch_bounds__(kPackThreads) void k_bitpack(Batch B) {
             const Code dc = dist_code(tok_dist(t));
             uint32_t lcode, llen, dcode, dlen;
             if (type == 2) {
-              lcode = bi->l_code[lc.code];
-              llen = bi->l_len[lc.code];
-              dcode = bi->d_code[dc.code];
-              dlen = bi->d_len[dc.code];
+              const uint32_t le = s_lc[lc.code], de = s_dc[dc.code];
+              lcode = le & 0xFFFFu;
+              llen = le >> 16;
+              dcode = de & 0xFFFFu;
+              dlen = de >> 16;
             } else {  // fixed codes LD:2826-2849
               llen = fixed_lit_bits(lc.code);
               const uint32_t c = lc.code <= 279 ? (lc.code - 256) : (0xC0 + lc.code - 280);
@@ -669,8 +677,9 @@ __global__ __launch_bounds__(kPackThreads) void k_bitpack(Batch B) {
             l += dc.ebits;
           } else {
             if (type == 2) {
-              v = bi->l_code[t];
-              l = bi->l_len[t];
+              const uint32_t le = s_lc[t];
+              v = le & 0xFFFFu;
+              l = le >> 16;
             } else {
               l = fixed_lit_bits(t);
               const uint32_t c = t <= 143 ? (0x30 + t) : (t <= 255 ? (0x190 + t - 144) : (t - 256));

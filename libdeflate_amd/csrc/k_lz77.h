@@ -138,16 +138,25 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
   // after the segment are the next segment's first bytes, or the zeros after the stream's end.
   // Global V is written from out0 on (what lies before is another segment's to write).
   const uint32_t total = (nv + kVPad) & ~3u;  // lo + nv + kVPad <= nvp + kVPad
+  // (whole dwords of the input where it is 4-byte aligned relative to V: the usual case)
+  const bool in_aligned = (((uintptr_t)in - D) & 3) == 0;
   for (uint32_t w = tid * 4; w < total; w += kSortThreads * 4) {
     uint32_t word = 0;
+    const uint32_t g0 = lo + w;
+    if (in_aligned && g0 >= D && g0 + 4 <= nv_all) {
+      word = *(const uint32_t *)(in + (g0 - D));
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t i = w + k, gi = lo + i;
-      uint32_t byte = 0;
-      if (gi < nv_all) byte = gi < D ? B.dict[gi] : in[gi - D];
-      if (i < nv) atomicAdd(&s_hist[byte], 1u);
-      word |= byte << (8 * k);
+      for (int k = 0; k < 4; k++) {
+        const uint32_t gi = g0 + k;
+        uint32_t byte = 0;
+        if (gi < nv_all) byte = gi < D ? B.dict[gi] : in[gi - D];
+        word |= byte << (8 * k);
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (w + k < nv) atomicAdd(&s_hist[(word >> (8 * k)) & 255u], 1u);
     if (w >= keep0) *(uint32_t *)(V + w) = word;
     if (V_LDS) *(uint32_t *)(ldsV + w) = word;
   }
