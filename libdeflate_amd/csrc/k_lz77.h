@@ -212,16 +212,18 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
         const bool valid = e[j] != 0xFFFFFFFFu;
         // lanes of this wave holding the same digit (stable rank = lanes below me)
         // (invalid lanes vote with digit 0; they are outside the initial mask, so a valid lane
-        // never counts them.  Written so that a bit costs v_bfe_i32 + v_cmp + two bit ops.)
+        // never counts them.  A bit costs v_bfe_i32 + v_cmp + two v_bitop3.)
         const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-        uint32_t mlo = (uint32_t)vm, mhi = (uint32_t)(vm >> 32);
+        uint32_t xlo = 0, xhi = 0;  // lanes whose digit differs from mine in some bit
 #pragma unroll
         for (int bit = 0; bit < 8; bit++) {
           const uint32_t m = (uint32_t)((int32_t)(d[j] << (31 - bit)) >> 31);  // all ones: my bit is set
           const unsigned long long bal = __builtin_amdgcn_ballot_w64((int32_t)m < 0);
-          mlo &= ~((uint32_t)bal ^ m);
-          mhi &= ~((uint32_t)(bal >> 32) ^ m);
+          // x |= bal ^ m, one v_bitop3 per half (truth table of a | (b ^ c))
+          xlo = __builtin_amdgcn_bitop3_b32(xlo, (uint32_t)bal, m, 0xF6);
+          xhi = __builtin_amdgcn_bitop3_b32(xhi, (uint32_t)(bal >> 32), m, 0xF6);
         }
+        const uint32_t mlo = (uint32_t)vm & ~xlo, mhi = (uint32_t)(vm >> 32) & ~xhi;
         const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
         const uint32_t old = s_cnt[wave][d[j]];  // same digit in this wave's earlier sub-rounds
