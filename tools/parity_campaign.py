@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""One-off randomized parity campaign on the GPU (a wider net than tests/: not collected by pytest): random
+batch shapes around the sort's narrow / wide / segmented thresholds, all lazy levels, with and without a
+dictionary, raw and zlib, compared byte for byte with the oracle and round-tripped on the device.
+usage: python tools/parity_campaign.py [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import ldtest as T
+from libdeflate_amd import LibDeflate as LD, batch as B, synth, _native as N
+
+N.init(0)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(20261110)
+pool = b"".join(r.tobytes() for r in synth.text_streams(8, 131072)) + T.golden("totalrp3.txt") + T.golden("encode_6bit_weakaura.txt")
+noise = bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
+dct = T.golden("dictionary32768.txt")
+dicts = {n: LD.CreateDictionary(dct[:n], n, T.o_adler32(dct[:n])) for n in (1, 300, 32768)}
+edges = [16384 - 48, 16384 - 47, 16336, 16400, 98304, 98305, 131072 - 48, 131072, 131105, 196608, 229376, 294912, 400000]
+
+
+def piece(n):
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        o = int(rng.integers(0, len(pool) - n)) if n < len(pool) else 0
+        return (pool * (n // len(pool) + 1))[o:o + n]
+    if kind == 1:
+        return (noise * (n // len(noise) + 1))[:n]
+    if kind == 2:
+        per = int(rng.integers(1, 40000))
+        return (noise[:per] * (n // per + 1))[:n]
+    if kind == 3:
+        return bytes([int(rng.integers(0, 256))]) * n
+    a = piece(n // 2)
+    return a + piece(n - len(a))
+
+
+t0 = time.time()
+rounds = checked = 0
+while time.time() - t0 < budget:
+    level = int(rng.choice([4, 5, 5, 6, 7, 8, 9, 1, 3]))
+    fmt = int(rng.integers(0, 2))
+    dn = int(rng.choice([0, 0, 1, 300, 32768]))
+    d = dicts.get(dn)
+    cnt = int(rng.integers(1, 7))
+    lens = [int(rng.choice(edges)) + int(rng.integers(-3, 4)) if rng.random() < 0.5 else int(rng.integers(0, 300000)) for _ in range(cnt)]
+    if level == 9:
+        lens = [min(x, 60000) for x in lens]  # (the oracle at level 9 is slow)
+    cases = [piece(max(0, x)) for x in lens]
+    got = B.compress_batch(cases, fmt=fmt, level=level, dictionary=d)
+    for s, g in zip(cases, got):
+        want = T.o_compress(s, zlib=bool(fmt), level=level, dict=dct[:dn] if dn else None)
+        assert g == want, ("MISMATCH", level, fmt, dn, len(s))
+        checked += 1
+    back = B.decompress_batch([c for c, _ in got], fmt=fmt, dictionary=d, max_out=max(max(len(c) for c in cases), 1))
+    assert [x for x, _ in back] == cases, ("ROUNDTRIP", level, fmt, dn, lens)
+    rounds += 1
+    if rounds % 10 == 0:
+        print("%d batches, %d streams checked, %.0f s" % (rounds, checked, time.time() - t0), flush=True)
+print("campaign ok: %d batches, %d streams byte-identical to the oracle and round-tripped" % (rounds, checked))
