@@ -651,7 +651,7 @@ constexpr int kParseRounds = kParseTile / kParseThreads;      // positions per t
 __device__ inline uint32_t parse_slot(uint32_t j) { return j + (j >> 5); }
 
 #ifndef LDH_PARSE_WAVES
-#define LDH_PARSE_WAVES 3  // 168 VGPRs: three workgroups per CU instead of two (5.4 -> 4.15 ms; at 4 the compiler's 128-register version is slower again)
+#define LDH_PARSE_WAVES 4  // four workgroups per CU (their LDS: 35 KB each)
 #endif
 __global__ __launch_bounds__(kParseThreads) __attribute__((amdgpu_waves_per_eu(LDH_PARSE_WAVES, LDH_PARSE_WAVES))) void k_parse_lazy(Batch B) {
   __shared__ uint32_t s_tok[kParseTile + kParseTile / 32 + 2];
@@ -677,52 +677,53 @@ __global__ __launch_bounds__(kParseThreads) __attribute__((amdgpu_waves_per_eu(L
 
   uint32_t tile_entry = xb0, tok_base = 0;
   for (uint32_t x0 = xb0; x0 <= xb1; x0 += kParseTile) {
-    // ---- candidate token of every position of the tile (all loads are issued before any
-    // of them is waited for; addresses are clamped rather than branched around)
-    uint32_t tk[kParseRounds];
-    {
-      uint32_t mm[kParseRounds];
+    // ---- stage the tile: one word per position = literal byte | (dist - 1) << 8 | length << 23
+    // (8 + 15 + 9 bits), so that step widths and tokens can both be derived from LDS alone.  Half a
+    // tile at a time: all loads of a half are issued before any of them is waited for; addresses
+    // are clamped rather than branched around.
 #pragma unroll
-      for (int r = 0; r < kParseRounds; r++) {
-        const uint32_t x = x0 + r * kParseThreads + c;
+    for (int h = 0; h < 2; h++) {
+      uint32_t mm[kParseRounds / 2], bb[kParseRounds / 2];
+#pragma unroll
+      for (int r = 0; r < kParseRounds / 2; r++) {
+        const uint32_t x = x0 + (h * (kParseRounds / 2) + r) * kParseThreads + c;
         const uint32_t xc = x <= xb1 ? x : xb1;
         mm[r] = m[xc];
-        tk[r] = Vd[xc];
+        bb[r] = Vd[xc];
       }
-      const uint32_t xe = x0 + kParseTile <= xb1 ? x0 + kParseTile : xb1;
-      const uint32_t edge = m[xe];
 #pragma unroll
-      for (int r = 0; r < kParseRounds; r++) {
-        const uint32_t x = x0 + r * kParseThreads + c;
-        s_tok[parse_slot(r * kParseThreads + c)] = x <= xb1 ? mm[r] : 0u;
+      for (int r = 0; r < kParseRounds / 2; r++) {
+        const uint32_t j = (h * (kParseRounds / 2) + r) * kParseThreads + c;
+        const uint32_t w = bb[r] | (((mm[r] - 1u) & 0x7FFFu) << 8) | ((mm[r] >> 16) << 23);
+        s_tok[parse_slot(j)] = x0 + j <= xb1 ? w : 0u;
       }
-      if (c == 0) s_tok[parse_slot(kParseTile)] = x0 + kParseTile <= xb1 ? edge : 0u;
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kParseRounds; r++) {
-      const uint32_t j = r * kParseThreads + c, x = x0 + j;
-      const uint32_t me = s_tok[parse_slot(j)], nx = s_tok[parse_slot(j + 1)];
-      const uint32_t pl = me >> 16, pd = me & 0xFFFF;
-      const uint32_t look = ((pl < max_lazy) & (x + 1 <= xb1)) ? nx >> 16 : 0u;
-      const bool usable = (pl > 3) | ((pl == 3) & (pd < 4096));
-      const uint32_t sel = 0u - (uint32_t)(usable & (look <= pl));  // all ones: match
-      tk[r] = (((1u << 31) | ((pl - 3) << 16) | (pd - 1)) & sel) | (tk[r] & ~sel);
+    if (c == 0) {  // the first position of the next tile: only its length is looked at
+      const uint32_t xe = x0 + kParseTile;
+      s_tok[parse_slot(kParseTile)] = xe <= xb1 ? (m[xe] >> 16) << 23 : 0u;
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kParseRounds; r++) s_tok[parse_slot(r * kParseThreads + c)] = tk[r];
     __syncthreads();
 
     // ---- the walk, by relaxation over chunks.  A lane keeps the 32 step widths of its chunk
     // in registers, so a (re-)walk is straight-line code with no memory access.
+    // step(x): match iff usable(L, dist) and look <= L, look = L(x+1) if L < max_lazy and x+1 is inside
+    // the block, else 0 (see above)
     const uint32_t cs = x0 + c * kParseChunk;
     const uint32_t clen = cs > xb1 ? 0u : (xb1 + 1 - cs < kParseChunk ? xb1 + 1 - cs : kParseChunk);
     uint32_t st[kParseChunk];
+    uint32_t is_match = 0;  // bit k: position cs + k, if the walk comes by, emits a match
+    {
+      uint32_t w = s_tok[c * (kParseChunk + 1)];
 #pragma unroll
-    for (int k = 0; k < (int)kParseChunk; k++) {
-      const uint32_t t = s_tok[c * (kParseChunk + 1) + k];
-      st[k] = (t >> 31) ? ((t >> 16) & 0x1FF) + 3 : 1u;
+      for (int k = 0; k < (int)kParseChunk; k++) {
+        const uint32_t wn = s_tok[c * (kParseChunk + 1) + k + 1 + ((k + 1) >> 5)];  // = parse_slot(c * 32 + k + 1)
+        const uint32_t pl = w >> 23, pd1 = (w >> 8) & 0x7FFFu;
+        const uint32_t look = ((pl < max_lazy) & (cs + k + 1 <= xb1)) ? wn >> 23 : 0u;
+        const bool mt = ((pl > 3) | ((pl == 3) & (pd1 < 4095u))) & (look <= pl);  // LD:1402-1404
+        st[k] = mt ? pl : 1u;
+        is_match |= mt ? 1u << k : 0u;
+        w = wn;
+      }
     }
     uint32_t entry = c == 0 ? tile_entry : cs, exit_x = 0, mask = 0;
     bool redo = true;
@@ -769,7 +770,9 @@ __global__ __launch_bounds__(kParseThreads) __attribute__((amdgpu_waves_per_eu(L
     while (mask) {
       const uint32_t bit = (uint32_t)__builtin_ctz(mask);
       mask &= mask - 1;
-      tok[o++] = s_tok[parse_slot(cs + bit - x0)];
+      const uint32_t j = cs + bit - x0;
+      const uint32_t w = s_tok[parse_slot(j)];
+      tok[o++] = ((is_match >> bit) & 1u) ? ((1u << 31) | (((w >> 23) - 3u) << 16) | ((w >> 8) & 0x7FFFu)) : (w & 0xFFu);
     }
     if (c == kParseThreads - 1) {
       s_tile_tot = s_off[c] + cnt;
