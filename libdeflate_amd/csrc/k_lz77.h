@@ -633,14 +633,14 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
 // and the parse is the walk x -> x + (match ? L(x) : 1) from the block's first position.
 // (tests compare this against the oracle's literal state machine.)
 //
-// One workgroup takes a block, tile by tile (8192 positions): the candidate token of every
-// position is computed with one lane per position (coalesced) into LDS; then the walk is
-// found by relaxation over 256 chunks of 32 positions: every lane walks its chunk from an
-// assumed entry position, entries are re-derived as the running maximum of the exits to
-// the left, lanes whose entry changed walk again, until nothing changes (chunk 0 is exact
-// from the start and every repeat fixes at least one more chunk; two or three repeats are
-// the rule).  Visited positions (a 32-bit mask per lane) are scanned and their tokens
-// written out.
+// One workgroup takes a block, tile by tile (8192 positions): L, Dist and the literal byte of
+// every position are staged into LDS as one packed word (one lane per position, coalesced); then
+// the walk is found by relaxation over 256 chunks of 32 positions: every lane derives the 32 step
+// widths of its chunk from LDS once, walks its chunk from an assumed entry position, entries are
+// re-derived as the running maximum of the exits to the left, lanes whose entry changed walk
+// again, until nothing changes (chunk 0 is exact from the start and every repeat fixes at least
+// one more chunk; two or three repeats are the rule).  Visited positions (a 32-bit mask per lane)
+// are scanned and their tokens, rebuilt from the packed words, written out.
 constexpr int kParseThreads = 256;
 constexpr uint32_t kParseChunk = 32;
 constexpr uint32_t kParseTile = kParseThreads * kParseChunk;  // 8192 positions

@@ -4,7 +4,7 @@ import csv, sys, collections
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", ", ";")  # (no commas inside a CSV field)
         if not k.startswith("ldh::"): continue
         acc[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1

@@ -10,5 +10,5 @@ print("kernel,calls,total_ms,avg_ms,share_of_ldh_pct,min_ms,max_ms")
 for r in rows:
     if r["Name"].startswith("ldh::"):
         t = int(r["TotalDurationNs"])
-        print("%s,%s,%.3f,%.4f,%.2f,%.4f,%.4f" % (r["Name"].split("(")[0], r["Calls"], t / 1e6, float(r["AverageNs"]) / 1e6,
+        print("%s,%s,%.3f,%.4f,%.2f,%.4f,%.4f" % (r["Name"].split("(")[0].replace(", ", ";"), r["Calls"], t / 1e6, float(r["AverageNs"]) / 1e6,
                                               100.0 * t / tot, int(r["MinNs"]) / 1e6, int(r["MaxNs"]) / 1e6))
