@@ -110,7 +110,31 @@ __global__ __launch_bounds__(kP6Threads) void k_print6_encode(const uint8_t *in,
   const uint64_t n = off[s + 1] - off[s];
   uint8_t *o = out + (uint64_t)s * out_stride;
   const uint64_t groups = n / 3;
-  for (uint64_t g = tid; g < groups; g += kP6Threads) {
+  // twelve bytes -> sixteen characters per thread and trip: aligned dword loads shifted into place
+  // (the input starts at any byte), one 16-byte store (out slots are 16-byte aligned)
+  const uint64_t quads = groups / 4;
+  {
+    const uintptr_t src = (uintptr_t)p;
+    const uint32_t sh = (uint32_t)(src & 3);
+    const uint32_t *w32 = (const uint32_t *)(src - sh);
+    uint4 *o128 = (uint4 *)o;
+    for (uint64_t g4 = tid; g4 < quads; g4 += kP6Threads) {
+      const uint32_t *q = w32 + 3 * g4;
+      const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = sh ? q[3] : 0u;  // (sh == 0: q[3] may lie past the input)
+      const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), bq = __builtin_amdgcn_alignbyte(w2, w1, sh),
+                     cq = __builtin_amdgcn_alignbyte(w3, w2, sh);
+      const uint32_t c24[4] = {a & 0xFFFFFFu, (a >> 24) | ((bq & 0xFFFFu) << 8), (bq >> 16) | ((cq & 0xFFu) << 16), cq >> 8};
+      uint32_t out4[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t c = c24[k];
+        out4[k] = (uint32_t)p6_char(c & 63) | ((uint32_t)p6_char((c >> 6) & 63) << 8) |
+                  ((uint32_t)p6_char((c >> 12) & 63) << 16) | ((uint32_t)p6_char((c >> 18) & 63) << 24);
+      }
+      o128[g4] = make_uint4(out4[0], out4[1], out4[2], out4[3]);
+    }
+  }
+  for (uint64_t g = quads * 4 + tid; g < groups; g += kP6Threads) {
     const uint32_t c = (uint32_t)p[3 * g] | ((uint32_t)p[3 * g + 1] << 8) | ((uint32_t)p[3 * g + 2] << 16);
     const uint32_t w = (uint32_t)p6_char(c & 63) | ((uint32_t)p6_char((c >> 6) & 63) << 8) |
                        ((uint32_t)p6_char((c >> 12) & 63) << 16) | ((uint32_t)p6_char((c >> 18) & 63) << 24);
@@ -147,16 +171,28 @@ __global__ __launch_bounds__(kP6Threads) void k_print6_decode(const uint8_t *in,
   }
   __syncthreads();
   // strip "^[%c ]+" and "[%c ]+$" (LD:3370-3371): first / one-past-last kept byte
-  unsigned long long lo = n, hi = 0;
-  for (uint64_t i = tid; i < n; i += kP6Threads) {
-    const uint32_t c = p[i];
-    if (!(c < 32 || c == 127 || c == ' ')) {
-      if (i < lo) lo = i;
-      if (i + 1 > hi) hi = i + 1;
+  // (scanned from both ends, 256 bytes at a time, until a kept byte shows: normally one trip each,
+  // instead of a pass over the whole input)
+  for (uint64_t c0 = 0; c0 < n; c0 += kP6Threads) {
+    const uint64_t i = c0 + tid;
+    bool keep = false;
+    if (i < n) {
+      const uint32_t c = p[i];
+      keep = !(c < 32 || c == 127 || c == ' ');
+      if (keep) atomicMin(&s_lo, (unsigned long long)i);
     }
+    if (__syncthreads_or(keep)) break;
   }
-  atomicMin(&s_lo, lo);
-  atomicMax(&s_hi, hi);
+  for (uint64_t c0 = 0; c0 < n; c0 += kP6Threads) {
+    const uint64_t k = c0 + tid;
+    bool keep = false;
+    if (k < n) {
+      const uint32_t c = p[n - 1 - k];
+      keep = !(c < 32 || c == 127 || c == ' ');
+      if (keep) atomicMax(&s_hi, (unsigned long long)(n - k));
+    }
+    if (__syncthreads_or(keep)) break;
+  }
   __syncthreads();
   const uint64_t b = s_lo < s_hi ? s_lo : 0, e = s_lo < s_hi ? s_hi : 0;
   const uint64_t m = e - b;
@@ -169,7 +205,34 @@ __global__ __launch_bounds__(kP6Threads) void k_print6_decode(const uint8_t *in,
   }
   const uint64_t groups = m / 4;
   uint32_t bad = 0;
-  for (uint64_t g = tid; g < groups; g += kP6Threads) {
+  // sixteen characters -> twelve bytes per thread and trip: aligned dword loads (shifted into place with
+  // v_alignbyte: the kept part starts at any byte) and three dword stores (out slots are 16-byte aligned)
+  const uint64_t quads = groups / 4;
+  {
+    const uintptr_t src = (uintptr_t)(p + b);
+    const uint32_t sh = (uint32_t)(src & 3);
+    const uint32_t *w32 = (const uint32_t *)(src - sh);
+    uint32_t *o32 = (uint32_t *)o;
+    for (uint64_t g4 = tid; g4 < quads; g4 += kP6Threads) {
+      const uint32_t *q = w32 + 4 * g4;
+      uint32_t w[5];
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = q[k];
+      w[4] = sh ? q[4] : 0u;  // (with sh == 0 the fifth dword is not part of the group and may lie past the input)
+      uint32_t c24[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t ch = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+        const int x1 = p6_value(ch & 255), x2 = p6_value((ch >> 8) & 255), x3 = p6_value((ch >> 16) & 255), x4 = p6_value(ch >> 24);
+        if ((x1 | x2 | x3 | x4) < 0) bad = 1;
+        c24[k] = ((uint32_t)x1 | ((uint32_t)x2 << 6) | ((uint32_t)x3 << 12) | ((uint32_t)x4 << 18)) & 0xFFFFFFu;
+      }
+      o32[3 * g4] = c24[0] | (c24[1] << 24);
+      o32[3 * g4 + 1] = (c24[1] >> 8) | (c24[2] << 16);
+      o32[3 * g4 + 2] = (c24[2] >> 16) | (c24[3] << 8);
+    }
+  }
+  for (uint64_t g = quads * 4 + tid; g < groups; g += kP6Threads) {
     const uint8_t *q = p + b + 4 * g;
     const int x1 = p6_value(q[0]), x2 = p6_value(q[1]), x3 = p6_value(q[2]), x4 = p6_value(q[3]);
     if ((x1 | x2 | x3 | x4) < 0) {
