@@ -317,27 +317,31 @@ __global__ __launch_bounds__(kCodecThreads) void k_codec_encode(const uint8_t *i
                                                                const CodecTables *T, uint8_t *out,
                                                                uint64_t out_stride, uint32_t *out_len) {
   __shared__ uint32_t s_w[kCodecThreads / kWave];
+  __shared__ uint32_t s_enc[256];  // enc0 | enc1 << 8 | enc_len << 16 (per byte they were three gathers from global memory)
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   const uint8_t *p = in + in_off[s];
   const uint64_t n = in_off[s + 1] - in_off[s];
   uint8_t *o = out + (uint64_t)s * out_stride;
+  for (uint32_t i = tid; i < 256; i += kCodecThreads)
+    s_enc[i] = (uint32_t)T->enc0[i] | ((uint32_t)T->enc1[i] << 8) | ((uint32_t)T->enc_len[i] << 16);
+  __syncthreads();
   uint64_t obase = 0;
   for (uint64_t t0 = 0; t0 < n; t0 += kCodecThreads * kCodecPer) {
     const uint64_t j0 = t0 + (uint64_t)tid * kCodecPer;
-    uint8_t b[kCodecPer];
+    uint32_t e[kCodecPer];
     uint32_t cnt = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kCodecPer; k++) {
-      b[k] = j0 + k < n ? p[j0 + k] : (uint8_t)0;
-      cnt += j0 + k < n ? T->enc_len[b[k]] : 0u;
+      e[k] = j0 + k < n ? s_enc[p[j0 + k]] : 0u;
+      cnt += e[k] >> 16;
     }
     uint32_t tot;
     uint64_t w = obase + codec_block_scan(cnt, tid, s_w, &tot);
 #pragma unroll
     for (uint32_t k = 0; k < kCodecPer; k++)
-      if (j0 + k < n) {
-        o[w++] = T->enc0[b[k]];
-        if (T->enc_len[b[k]] == 2) o[w++] = T->enc1[b[k]];
+      if (e[k] >> 16) {
+        o[w++] = (uint8_t)e[k];
+        if ((e[k] >> 16) == 2) o[w++] = (uint8_t)(e[k] >> 8);
       }
     obase += tot;
   }
@@ -361,27 +365,18 @@ __global__ __launch_bounds__(kCodecThreads) void k_codec_decode_pass(const uint8
   const uint8_t *p = first ? in + in_off[s] : prev + (uint64_t)s * stride;
   const uint64_t n = first ? in_off[s + 1] - in_off[s] : prev_len[s];
   uint8_t *o = out + (uint64_t)s * stride;
-  if (first) {
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-    uint32_t bad = 0;
-    for (uint64_t j = tid; j < n; j += kCodecThreads) bad |= T->reserved[p[j]];
-    if (bad) s_bad = 1;
-    __syncthreads();
-    if (s_bad) {  // LD:3048
-      if (tid == 0) {
-        ok[s] = 0;
-        out_len[s] = 0;
-      }
-      return;
-    }
-    if (tid == 0) ok[s] = 1;
-  } else if (!ok[s]) {
+  // this pass's tables in LDS: dec (escape suffix -> byte, 0xFFFF none) | map_back << 16 | reserved << 24
+  __shared__ uint32_t s_tab[256];
+  if (!first && !ok[s]) {
     if (tid == 0) out_len[s] = 0;
     return;
   }
+  if (tid == 0) s_bad = 0;
+  for (uint32_t i = tid; i < 256; i += kCodecThreads)
+    s_tab[i] = (uint32_t)T->pass_dec[pass][i] | ((uint32_t)T->map_back[i] << 16) | ((uint32_t)T->reserved[i] << 24);
+  __syncthreads();
   const uint8_t E = T->pass_escape[pass];
-  const uint16_t *dec = T->pass_dec[pass];
+  uint32_t bad = 0;  // (first pass) a reserved byte anywhere in the input: nil (LD:3048), found while reading
   uint64_t obase = 0;
   for (uint64_t t0 = 0; t0 < n; t0 += kCodecThreads * kCodecPer) {
     const uint64_t j0 = t0 + (uint64_t)tid * kCodecPer;
@@ -393,7 +388,11 @@ __global__ __launch_bounds__(kCodecThreads) void k_codec_decode_pass(const uint8
       uint8_t x = 0;
       if (j >= 1 && j - 1 < n) {
         x = p[j - 1];
-        if (first) x = T->map_back[x];
+        if (first) {
+          const uint32_t t = s_tab[x];
+          bad |= t >> 24;
+          x = (uint8_t)(t >> 16);
+        }
       }
       b[k] = x;
     }
@@ -403,9 +402,10 @@ __global__ __launch_bounds__(kCodecThreads) void k_codec_decode_pass(const uint8
     for (uint32_t k = 0; k < kCodecPer; k++) {
       const uint64_t j = j0 + k;
       const uint8_t x = b[k + 1];
-      const bool starts = j + 1 < n && x == E && dec[b[k + 2]] != 0xFFFF;
-      const bool second = j >= 1 && b[k] == E && dec[x] != 0xFFFF;
-      val[k] = starts ? (uint8_t)dec[b[k + 2]] : x;
+      const uint32_t dn = s_tab[b[k + 2]] & 0xFFFFu, dx = s_tab[x] & 0xFFFFu;
+      const bool starts = j + 1 < n && x == E && dn != 0xFFFF;
+      const bool second = j >= 1 && b[k] == E && dx != 0xFFFF;
+      val[k] = starts ? (uint8_t)dn : x;
       if (j < n && !second) {
         keepm |= 1u << k;
         cnt++;
@@ -417,6 +417,15 @@ __global__ __launch_bounds__(kCodecThreads) void k_codec_decode_pass(const uint8
     for (uint32_t k = 0; k < kCodecPer; k++)
       if ((keepm >> k) & 1) o[w++] = val[k];
     obase += tot;
+  }
+  if (first) {
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (tid == 0) {
+      ok[s] = s_bad ? 0 : 1;
+      out_len[s] = s_bad ? 0u : (uint32_t)obase;
+    }
+    return;
   }
   if (tid == 0) out_len[s] = (uint32_t)obase;
 }

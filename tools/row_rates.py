@@ -50,6 +50,43 @@ print("print6 decode:", pr, "-> %.0f GB/s of output, %.0f GB/s read+written; exa
       (nbytes / 1e6 / t, nbytes * 7 / 3 / 1e6 / t, bool(torch.equal(dec, data)) and int(ok.sum()) == S), flush=True)
 del enc, packed, dec
 
+# the WoW addon channel codec on the compressed streams of the same batch (what a WoW caller sends): codec:Encode / codec:Decode
+bt0 = B.DeviceBatch(data, off, L)
+st0 = N.lib.ldh_compress_bound(L)
+comp0 = torch.empty(S * st0, dtype=torch.uint8, device=dev)
+clen0 = torch.zeros(S, dtype=torch.int32, device=dev)
+pad0 = torch.zeros(S, dtype=torch.uint8, device=dev)
+torch.cuda.synchronize()
+B.device_compress(bt0, comp0, st0, clen0, pad0, fmt=0, level=5)
+B.sync()
+lens = clen0.to(torch.int64)
+coff = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+coff[1:] = torch.cumsum(lens, 0)
+idx = torch.arange(st0, device=dev)[None, :] < lens[:, None]
+cpacked = comp0.view(S, st0)[idx].contiguous()
+cbytes = int(coff[-1].item())
+codec = LD._addon_codec()
+es = (2 * int(lens.max().item()) + 15) // 16 * 16
+eout = torch.empty(S * es, dtype=torch.uint8, device=dev)
+elen = torch.zeros(S, dtype=torch.int32, device=dev)
+pr = prof(lambda: N.check(N.lib.ldh_codec_encode_batch_dev(codec.handle(), cpacked.data_ptr(), coff.data_ptr(), S, eout.data_ptr(), es, elen.data_ptr())))
+t = sum(pr.values())
+ebytes = int(elen.sum().item())
+print("addon codec encode: %d B -> %d B:" % (cbytes, ebytes), pr, "-> %.0f GB/s read+written" % ((cbytes + ebytes) / 1e6 / t), flush=True)
+l2 = elen.to(torch.int64)
+eoff = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+eoff[1:] = torch.cumsum(l2, 0)
+epacked = eout.view(S, es)[torch.arange(es, device=dev)[None, :] < l2[:, None]].contiguous()
+ds = (int(lens.max().item()) + 16 + 15) // 16 * 16
+dout = torch.empty(S * ds, dtype=torch.uint8, device=dev)
+dlen = torch.zeros(S, dtype=torch.int32, device=dev)
+dok = torch.zeros(S, dtype=torch.uint8, device=dev)
+pr = prof(lambda: N.check(N.lib.ldh_codec_decode_batch_dev(codec.handle(), epacked.data_ptr(), eoff.data_ptr(), S, dout.data_ptr(), ds, dlen.data_ptr(), dok.data_ptr())))
+t = sum(pr.values())
+same = bool(torch.equal(dlen, clen0)) and int(dok.sum()) == S and bool(torch.equal(dout.view(S, ds)[torch.arange(ds, device=dev)[None, :] < lens[:, None]], cpacked))
+print("addon codec decode:", pr, "-> %.0f GB/s read+written; exact=%s" % ((cbytes + ebytes) / 1e6 / t, same), flush=True)
+del comp0, eout, dout, cpacked, epacked, idx
+
 # BASELINE configs[1] shape: 65536 streams of 4096 bytes
 S2, L2 = 65536, 4096
 bt = B.DeviceBatch(data[: S2 * L2], torch.arange(S2 + 1, dtype=torch.int64, device=dev) * L2, L2)
