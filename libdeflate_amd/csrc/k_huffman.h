@@ -389,8 +389,20 @@ __global__ void k_plan(Batch B) {
   uint64_t total = 0;
   if (B.fmt == 1) total = B.dict ? 48 : 16;  // CMF, FLG, DICTID (LD:1976-2001)
   out32[0] = 0;  // the zlib header rides with block 0 and is OR-ed in as well
+  // (a long stream has thousands of blocks: their sizes are fetched eight blocks ahead of the serial
+  // walk, which would otherwise pay one memory round trip per block)
+  constexpr uint32_t kAhead = 8;
+  uint32_t fixq[kAhead], dynq[kAhead];
   for (uint32_t b = 0; b < nblk; b++) {
     BlockInfo *bi = &B.blocks[(size_t)s * B.max_blocks + b];
+    if (b % kAhead == 0 && B.level != 0) {
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; k++) {
+        const uint32_t bb = b + k < nblk ? b + k : nblk - 1;
+        fixq[k] = bi[bb - b].fix_bits;
+        dynq[k] = bi[bb - b].dyn_bits;
+      }
+    }
     const uint32_t bs = block_start(b), be = block_end(b, n);
     const uint64_t t3 = total + 3;
     const uint64_t store = 3 + (8 - t3 % 8) % 8 + 32 + (uint64_t)(be + 1 - bs) * 8;  // LD:1718-1727
@@ -400,7 +412,13 @@ __global__ void k_plan(Batch B) {
       type = 0;
       bits = store;
     } else {
-      const uint64_t fix = bi->fix_bits, dyn = bi->dyn_bits;
+      uint64_t fix = 0, dyn = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; k++)
+        if (b % kAhead == k) {
+          fix = fixq[k];
+          dyn = dynq[k];
+        }
       uint64_t mn = store;
       if (fix < mn) mn = fix;
       if (dyn < mn) mn = dyn;
