@@ -467,7 +467,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   constexpr uint32_t steps_per_round = kMatchSteps;
   unsigned long long act = 0, pm = 0, pend = 0, seed = 0;
   bool exhausted = false;
-  uint32_t q = 0, vb = 0, cb = 0, best = 0, bdist = 0, maxlen = 0, t2 = 0, dn = 0xFFFFu;
+  uint32_t q = 0, vb = 0, cb = 0, maxlen = 0, t2 = 0, dn = 0xFFFFu;
+  uint32_t res = 0;  // best length << 16 | its distance: the word that is stored; 0 = no match yet
   uint32_t d1 = 0;   // candidates the walk may still evaluate after the current one (LD:1362)
   uint32_t off = 0;  // best ? best - 1 : 0
   int32_t lo = 0;    // vb - 32768: the farthest candidate inside the window (LD:1365)
@@ -505,27 +506,26 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       if (cm & lane_bit) {
         const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
         uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
-        if (x == 0) {
-          while (L < maxlen) {  // (bytes are staged 280 past the tile's end: reading past maxlen is safe)
-            const uint64_t y = lds_load8(lbytes, cb + L) ^ lds_load8(lbytes, vb + L);
-            if (y) {
-              L += (uint32_t)__builtin_ctzll(y) >> 3;
-              break;
-            }
-            L += 8;
-          }
+        // the tail of a long match, 8 bytes per trip: a wave-uniform loop over the lanes still equal
+        // (per-lane `break`s cost some 25 scalar instructions of mask bookkeeping per trip)
+        unsigned long long going = ballot64((x == 0) & (L < maxlen));
+        while (going) {  // (bytes are staged 280 past the tile's end: reading past maxlen is safe)
+          const bool on = __builtin_amdgcn_inverse_ballot_w64(going);
+          const uint64_t y = lds_load8(lbytes, cb + L) ^ lds_load8(lbytes, vb + L);
+          const uint32_t adv = y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8u;
+          L += on ? adv : 0u;
+          going &= ballot64((y == 0) & (L < maxlen));
         }
         if (L > maxlen) L = maxlen;
-        if (L > best) {  // LD:1385 strict: nearest of equal lengths wins
-          best = L;
-          bdist = vb - cb;
-          off = best - 1;
+        if ((L << 16) > res) {  // L > best (distances are below 65536); LD:1385 strict: nearest of equal lengths wins
+          res = (L << 16) | (vb - cb);
+          off = L - 1;
           t2 = lds_load2(lbytes, vb + off);
         }
       }
       // a match of maxlen cannot be beaten (the walk has no side effects, so ending it early
       // leaves the result unchanged)
-      const unsigned long long open = ballot64((best < nice) & (best < maxlen));
+      const unsigned long long open = ballot64(((res >> 16) < nice) & ((res >> 16) < maxlen));
       unsigned long long go;
       LDH_HOP(cm & open, dn, go);
       act = (act & ~cm) | go;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
     // gets no position or one that is not searched (LD:1349): that one keeps best = 0 and is
     // stored like any other result at the lane's next refill.)
     const bool mine = (idle & lane_bit) != 0;
-    if (mine && (pend & lane_bit)) mout[q] = best ? ((best << 16) | bdist) : 0u;
+    if (mine && (pend & lane_bit)) mout[q] = res;
     const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
     const bool has_pos = mine & (my < q1);
     const uint32_t myc = has_pos ? my : q0;  // (keeps the LDS addresses below inside the staged range)
@@ -565,8 +565,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
       tw = twn;
       t2 = t2n;
       d1 = (uint32_t)cfg.max_chain - 1;  // Q3
-      best = 0u;
-      bdist = 0u;
+      res = 0u;
       off = 0u;
       dn = dnn;
     }
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t 
   }
 #undef LDH_HOP
 #undef LDH_DEC_MASKED
-  if (pend & lane_bit) mout[q] = best ? ((best << 16) | bdist) : 0u;
+  if (pend & lane_bit) mout[q] = res;
 }
 
 // ------------------------------------------------------------------ k_parse_lazy
