@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void k_histogram(Batch B) {
 }
 
 // ------------------------------------------------------------------ k_huffman
+// (4.9 KB with the kernel's own arrays, so that 32 wavefronts share a CU: the heap is a chain of
+// dependent LDS accesses on one lane, and what the CU gets done is the number of heaps in flight.
+// Tree node i < nleaf is the leaf leafs[i]; the codes reuse the heap's slots once the tree stands.)
 struct HuffScratch {
-  int16_t sym[576];
   int16_t leafs[288];
-  uint32_t hp[292];  // heap slots: weight << 10 | node
+  uint32_t hp[292];  // heap slots: weight << 10 | node; afterwards the codes (uint16_t[288])
   uint32_t cnt[288];  // counts of the alphabet being built
   uint8_t len[288];
-  uint16_t code[288];
   int bl_count[17];
   int next_code[17];
   int16_t parent[576];
@@ -98,14 +99,12 @@ __device__ inline void hs_push(HuffScratch &S, uint32_t e, int heap_size) {
   S.hp[pos] = e;
 }
 
-// GetHuffmanBitlenAndCode (LD:968-1085) over S.cnt[0..nsym); results in S.len / S.code.
+// GetHuffmanBitlenAndCode (LD:968-1085) over S.cnt[0..nsym); results in S.len and the codes (uint16_t[nsym] over S.hp).
 // Called by the whole wavefront; the leaf sort is done by all lanes, the heap by lane 0.
 // Returns max_non_zero_bitlen_symbol (-1 if no symbol).
 __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lane) {
-  for (int i = lane; i < nsym; i += kWave) {
-    S.len[i] = 0;
-    S.code[i] = 0;
-  }
+  uint16_t *const code = (uint16_t *)S.hp;  // (zeroed and written after the heap is done with its slots)
+  for (int i = lane; i < nsym; i += kWave) S.len[i] = 0;
   // rank of every used symbol in (count, symbol) order (LD:953-955, 1002)
   int nleaf = 0;
   for (int base = 0; base < nsym; base += kWave) {
@@ -126,13 +125,11 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
   if (lane == 0) {
     if (nleaf == 1) {  // LD:992-1000
       const int sy = S.leafs[0];
-      S.len[sy] = 1;
-      S.code[sy] = 0;
+      S.len[sy] = 1;  // (its code, 0, is set with all the others below)
       max_nz = sy;
     } else if (nleaf >= 2) {
       for (int i = 0; i < nleaf; i++) {
         const int sy = S.leafs[i];
-        S.sym[i] = (int16_t)sy;
         S.hp[i + 1] = (S.cnt[sy] << 10) | (uint32_t)i;
       }
       int heap_size = nleaf, nnodes = nleaf;
@@ -141,7 +138,6 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
         heap_size--;
         const uint32_t r = hs_pop(S, heap_size);
         heap_size--;
-        S.sym[nnodes] = -1;
         S.parent[l & 1023] = (int16_t)nnodes;
         S.parent[r & 1023] = (int16_t)nnodes;
         hs_push(S, (((l >> 10) + (r >> 10)) << 10) | (uint32_t)nnodes, heap_size);
@@ -153,6 +149,7 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
     }
   }
   __syncthreads();
+  for (int i = lane; i < nsym; i += kWave) code[i] = 0;
   if (nleaf >= 2) {
     // Depths (LD:1021-1053).  The reference walks the tree breadth first, but what it computes does
     // not depend on the order: a node's depth, `overflow` = number of nodes (internal ones too) deeper
@@ -169,7 +166,7 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
         over++;
         depth = max_bitlen;
       }
-      const int sy = S.sym[i];
+      const int sy = i < nleaf ? S.leafs[i] : -1;
       if (sy >= 0) {
         S.len[sy] = (uint8_t)depth;
         atomicAdd(&S.bl_count[depth], 1);
@@ -227,7 +224,7 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
       const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (active) {
         const uint32_t c = (uint32_t)S.next_code[len] + rank;
-        S.code[sy] = (uint16_t)(__brev(c) >> (32 - len));
+        code[sy] = (uint16_t)(__brev(c) >> (32 - len));
       }
       __syncthreads();
       if (active && rank == 0) S.next_code[len] += (int)__popcll(mask);
@@ -259,7 +256,7 @@ __global__ __launch_bounds__(kWave) void k_huffman(Batch B) {
   for (int i = lane; i < 286; i += kWave) {
     const uint32_t c = S.cnt[i], l = S.len[i];
     bi->l_len[i] = (uint8_t)l;
-    bi->l_code[i] = S.code[i];
+    bi->l_code[i] = ((const uint16_t *)S.hp)[i];
     s_llen[i] = (uint8_t)l;
     const uint32_t eb = i > 256 ? len_extra_bits(i) : 0;
     dyn += (uint64_t)c * (l + eb);
@@ -273,7 +270,7 @@ __global__ __launch_bounds__(kWave) void k_huffman(Batch B) {
   for (int i = lane; i < 30; i += kWave) {
     const uint32_t c = S.cnt[i], l = S.len[i];
     bi->d_len[i] = (uint8_t)l;
-    bi->d_code[i] = S.code[i];
+    bi->d_code[i] = ((const uint16_t *)S.hp)[i];
     s_dlen[i] = (uint8_t)l;
     const uint32_t eb = dist_extra_bits(i);
     dyn += (uint64_t)c * (l + eb);
@@ -349,7 +346,7 @@ __global__ __launch_bounds__(kWave) void k_huffman(Batch B) {
   huff_build(S, 19, 7, lane);
   if (lane < 19) {
     bi->cl_len[lane] = S.len[lane];
-    bi->cl_code[lane] = (uint8_t)S.code[lane];
+    bi->cl_code[lane] = (uint8_t)((const uint16_t *)S.hp)[lane];
     const uint32_t c = S.cnt[lane];
     const uint32_t eb = lane >= 16 ? (uint32_t)rle_extra_bitlen((int)lane) : 0;
     rle_bits_extra = c * (S.len[lane] + eb);
