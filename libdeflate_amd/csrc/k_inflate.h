@@ -358,8 +358,11 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
   bool have = false;
   // match copies in flight: bytes loaded in one round are stored in the next (plen 0: free)
-  constexpr int kPend = 4;
-  uint32_t pval[kPend] = {0, 0, 0, 0}, plen[kPend] = {0, 0, 0, 0}, pdst[kPend] = {0, 0, 0, 0};
+#ifndef LDH_INFLATE_PEND
+#define LDH_INFLATE_PEND 1  // deferred copies per round (0 / 1 / 2 / 4 / 6: 14.07 / 13.9 / 14.6 / 14.7 / 15.6 ms per GiB: a slot costs its checks in every round)
+#endif
+  constexpr int kPend = LDH_INFLATE_PEND;
+  uint32_t pval[kPend + 1] = {}, plen[kPend + 1] = {}, pdst[kPend + 1] = {};  // (+1: kPend may be 0)
   uint32_t pend_lo = 0xFFFFFFFFu;  // lowest output position with a store in flight
   for (;;) {
     if (!have || rel >= 58 * 32) {
