@@ -486,9 +486,13 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
           const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
           const uint32_t d = __builtin_amdgcn_readlane(dist, j);
           const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
-          for (uint32_t i = lane; i < len; i += kWave) {
-            const uint32_t a = dst + i;
-            out[a] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+          if (d <= dst) {  // (uniform) the source lies in the output: no per-lane pointer select
+            for (uint32_t i = lane; i < len; i += kWave) out[dst + i] = out[dst - d + i];
+          } else {
+            for (uint32_t i = lane; i < len; i += kWave) {
+              const uint32_t a = dst + i;
+              out[a] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+            }
           }
         }
       } else {
@@ -501,9 +505,13 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
           const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          for (uint32_t i = lane; i < len; i += kWave) {
-            const uint32_t a = dst + (d >= len ? i : (i % d));
-            out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+          if (d >= len && d <= dst) {  // (uniform) no overlap with itself, source in the output
+            for (uint32_t i = lane; i < len; i += kWave) out[dst + i] = out[dst - d + i];
+          } else {
+            for (uint32_t i = lane; i < len; i += kWave) {
+              const uint32_t a = dst + (d >= len ? i : (i % d));
+              out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+            }
           }
         } while (mm);
       }
