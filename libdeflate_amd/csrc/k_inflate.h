@@ -359,7 +359,9 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   bool have = false;
   // match copies in flight: bytes loaded in one round are stored in the next (plen 0: free)
 #ifndef LDH_INFLATE_PEND
-#define LDH_INFLATE_PEND 1  // deferred copies per round (0 / 1 / 2 / 4 / 6: 14.07 / 13.9 / 14.6 / 14.7 / 15.6 ms per GiB: a slot costs its checks in every round)
+#define LDH_INFLATE_PEND 0  // match copies deferred to the next round (so that their loads overlap its decode).  Slots cost their
+// checks in every round: 4 -> 1 was worth 0.8 ms per GiB, and with the uniform copy loops below none at all is fastest
+// (0 / 1 / 2: 13.0 / 13.3 / 13.6 ms); the mechanism stays for batches too small to hide the loads behind other waves.
 #endif
   constexpr int kPend = LDH_INFLATE_PEND;
   uint32_t pval[kPend + 1] = {}, plen[kPend + 1] = {}, pdst[kPend + 1] = {};  // (+1: kPend may be 0)
