@@ -108,12 +108,34 @@ def main():
     ap.add_argument("--level", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-levels", action="store_true", help="skip the one-step runs at levels 1 and 8")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check (CPU, gloo): start the ranks, run the barrier / MAX-over-ranks protocol around "
+                         "empty steps and print the line with value null; no GPU work")
     args = ap.parse_args()
+
+    from libdeflate_amd import shard
+    rank, local_rank, world = shard.env_world()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process becomes the launcher of N rank processes (one per GPU).  It has
+        # made no GPU call (torch is not even imported yet) and makes none: it waits and hands on the exit code.
+        sys.exit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if args.rendezvous_only:
+        import torch
+        dist = shard.init("gloo")
+        dt = shard.timed_steps(lambda: None, args.steps, args.warmup, lambda: None, dist, torch, "cpu")
+        ok = shard.all_true(True, dist, torch, "cpu")
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous only", "value": None, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": dt * 1e3 / max(args.steps, 1), "verified": ok}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import numpy as np
     import torch
-    from libdeflate_amd import shard
-    rank, local_rank, world = shard.env_world()
     dist = shard.init("nccl", torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -143,6 +165,9 @@ def main():
         B.sync()
         torch.cuda.synchronize()
 
+    # the library enqueues on its own stream: torch's kernels that produced `data`, `off` and the fills above must
+    # have completed before the first *_dev call reads them
+    torch.cuda.synchronize()
     # untimed warm-up, then the profiled + timed steps (barrier + sync on both sides, MAX over ranks)
     shard.timed_steps(step, 0, args.warmup, dev_sync, dist, torch, dev)
     B.profile(True)

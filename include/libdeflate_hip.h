@@ -12,8 +12,8 @@
  * ldh_last_error()).  Per-stream *data* results (LibDeflate's inflate status codes,
  * SURVEY Q11) are written to status[] and never make the call itself fail.
  *
- * Threading: the library keeps one HIP stream and one workspace per process; calls are
- * serialised by an internal mutex.  Host-pointer entry points synchronise before they
+ * Threading: the library keeps one HIP stream and one workspace per context (ldh_init: one
+ * context; ldh_init_devices: one per GPU); calls on a context are serialised by its mutex.  Host-pointer entry points synchronise before they
  * return.  *_dev entry points only enqueue work on the library stream (ldh_stream());
  * call ldh_sync() before reading results on the host.
  */
@@ -42,6 +42,7 @@ extern "C" {
 #define LDH_E_HIP (-102)
 #define LDH_E_NOMEM (-103)
 #define LDH_E_CAPACITY (-104) /* caller's output slot too small */
+#define LDH_E_TOO_LONG (-105) /* ldh_sync: a *_dev compress call met streams longer than its max_in_len */
 
 /* Extra per-stream status beyond LibDeflate's codes: output slot too small (puff's 1). */
 #define LDH_STATUS_OUTPUT_FULL 1
@@ -49,12 +50,29 @@ extern "C" {
 typedef struct ldh_dict ldh_dict;
 
 /* ---- lifecycle ------------------------------------------------------------- */
-int ldh_init(int device); /* selects the HIP device; idempotent for the same device */
+int ldh_init(int device); /* one context (streams + workspace) on this HIP device; idempotent for the same device */
 void ldh_shutdown(void);
 int ldh_device_count(void);
 const char *ldh_last_error(void);
-void *ldh_stream(void); /* hipStream_t the *_dev calls enqueue on */
+void *ldh_stream(void); /* hipStream_t the *_dev calls enqueue on (current context) */
+/* Waits for the current context's stream.  LDH_E_TOO_LONG if a *_dev compress call since the last
+ * ldh_sync met streams longer than its max_in_len: those have out_len 0 (they are never truncated). */
 int ldh_sync(void);
+
+/* ---- one library, many GPUs (host-side scatter, no inter-GPU collective) --------------
+ * No reference counterpart (the reference is single-threaded, one string per call).
+ * ldh_init_devices makes a pool of contexts, one per listed device (NULL / 0: every visible device; a
+ * device listed twice gets two contexts).  From then on ldh_compress_batch and ldh_decompress_batch cut
+ * their batch into contiguous, byte-balanced parts (ldh_partition_by_bytes), one per context, run them on
+ * one host thread + three HIP streams per context, and results land in the caller's one buffer.  All other
+ * calls (single strings, *_dev, profiling) use the context of ldh_init() -- the pool's first one if
+ * ldh_init was not called -- or the pool member this thread chose with ldh_use_context(index) (-1: back to
+ * the default).  Device pointers passed to *_dev calls must belong to the current context's device. */
+int ldh_init_devices(const int *devices, int n);
+int ldh_pool_size(void);
+int ldh_use_context(int index);
+/* first[0..parts]: part p takes streams [first[p], first[p+1]); pure host arithmetic. */
+int ldh_partition_by_bytes(const uint64_t *in_off, size_t count, int parts, size_t *first);
 
 /* Largest output CompressDeflate/CompressZlib can produce for n input bytes at any
  * level/strategy; also the required out_stride granularity (multiple of 16). */

@@ -12,6 +12,7 @@ import ctypes as C
 from . import _native as N
 
 _STRATEGY = {None: 0, "fixed": 1, "huffman_only": 2, "dynamic": 3}
+MAX_OUT = 0xFFF00000  # k_inflate's clamp on one stream's output slot
 
 
 def _lua_type(v):
@@ -190,8 +191,10 @@ class _LibDeflate(object):
             out = (C.c_ubyte * cap)()
             ol, bl, st = C.c_size_t(), C.c_size_t(), C.c_int()
             N.check(N.lib.ldh_decompress(_buf(s), len(s), fmt, h, out, cap, C.byref(ol), C.byref(bl), C.byref(st)))
-            if st.value == 1:  # LDH_STATUS_OUTPUT_FULL: Lua strings simply grow
-                cap *= 4
+            if st.value == 1:  # LDH_STATUS_OUTPUT_FULL: Lua strings simply grow -- up to the library's limit
+                if cap >= MAX_OUT:
+                    raise N.LdhError("output of 4 GiB or more is not supported")
+                cap = min(cap * 4, MAX_OUT)
                 continue
             if st.value != 0:
                 return None, st.value

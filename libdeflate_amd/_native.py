@@ -15,6 +15,26 @@ if not os.path.exists(SO_PATH):
         "libdeflate_hip.so is missing (%s). Build it with `make -C libdeflate_amd/csrc`; "
         "this package has no CPU fallback." % SO_PATH)
 
+
+
+def _share_torch_hip_runtime():
+    """torch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's, but torch asks for it by another
+    name), so a process that loads libdeflate_hip.so BEFORE torch ends up with two HIP runtimes, and the second
+    one finds no device.  Loading torch's copy first (without importing torch) makes both resolve to that one,
+    whatever the import order; without torch installed the system runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+_share_torch_hip_runtime()
 lib = C.CDLL(SO_PATH)
 
 u8p, u32p, u64p, i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
@@ -27,6 +47,10 @@ _SIGS = {
     "ldh_last_error": (C.c_char_p, []),
     "ldh_stream": (C.c_void_p, []),
     "ldh_sync": (C.c_int, []),
+    "ldh_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "ldh_pool_size": (C.c_int, []),
+    "ldh_use_context": (C.c_int, [C.c_int]),
+    "ldh_partition_by_bytes": (C.c_int, [u64p, sz, C.c_int, C.c_void_p]),
     "ldh_compress_bound": (sz, [sz]),
     "ldh_dict_create": (C.c_void_p, [u8p, sz]),
     "ldh_dict_free": (None, [C.c_void_p]),
@@ -92,3 +116,25 @@ def init(device=0):
         return
     check(lib.ldh_init(device))
     _inited = device
+
+
+def init_devices(devices=None):
+    """A pool of contexts, one per listed device (None: every visible GPU; a device may be listed twice):
+    the host-pointer batch calls then split their streams over it by bytes (include/libdeflate_hip.h)."""
+    global _inited
+    if devices:
+        arr = (C.c_int * len(devices))(*devices)
+        check(lib.ldh_init_devices(arr, len(devices)))
+    else:
+        check(lib.ldh_init_devices(None, 0))
+    if _inited is None:
+        _inited = devices[0] if devices else 0
+
+
+def partition_by_bytes(in_off, parts):
+    """first[0..parts] of ldh_partition_by_bytes for a numpy uint64 offsets array (host arithmetic only)."""
+    import numpy as np
+    off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    first = (sz * (parts + 1))()
+    check(lib.ldh_partition_by_bytes(off.ctypes.data, len(off) - 1, parts, first))
+    return [int(x) for x in first]

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .LibDeflate import _STRATEGY
+from .LibDeflate import _STRATEGY, MAX_OUT
 
 
 def _concat(strings):
@@ -39,7 +39,9 @@ def compress_batch(strings, fmt=0, level=None, strategy=None, dictionary=None):
 
 
 def decompress_batch(strings, fmt=0, dictionary=None, max_out=None):
-    """Returns [(bytes, bytes_left)] or [(None, status)] per stream."""
+    """Returns [(bytes, bytes_left)] or [(None, status)] per stream.  `max_out` is a hard limit on one result's
+    size (a stream that needs more gives (None, 1) = LDH_STATUS_OUTPUT_FULL); without it the slots grow (x4) until
+    every stream fits, up to the library's 4 GiB limit."""
     N.init()
     n = len(strings)
     if n == 0:
@@ -63,14 +65,14 @@ def decompress_batch(strings, fmt=0, dictionary=None, max_out=None):
         again = []
         for k, i in enumerate(pending):
             st = int(status[k])
-            if st == 1:
+            if st == 1 and max_out is None and cap < MAX_OUT:
                 again.append(i)
             elif st != 0:
                 results[i] = (None, st)
             else:
                 results[i] = (out[k * stride: k * stride + int(out_len[k])].tobytes(), int(left[k]))
         pending = again
-        cap *= 4
+        cap = min(cap * 4, MAX_OUT)
     return results
 
 

@@ -445,6 +445,12 @@ __global__ void k_plan(Batch B) {
     out32[(total + pad + 31) >> 5] = 0;  // trailer may end in a fresh word
     bytes += 4;
   }
+  if (B.in_off[s + 1] - B.in_off[s] > (uint64_t)B.max_len) {  // not truncated silently: rejected
+    atomicAdd(B.too_long, 1u);
+    B.out_len[s] = 0;
+    B.pad_bits[s] = 0;
+    return;
+  }
   B.out_len[s] = (uint32_t)bytes;
   B.pad_bits[s] = (uint8_t)(B.fmt == 1 ? 0 : pad);
 }

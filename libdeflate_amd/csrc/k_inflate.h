@@ -384,7 +384,9 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       rel = (uint32_t)absbit & 31;
       bp0 = (int64_t)bp - (int64_t)rel;
       const int64_t l = (int64_t)nbits - bp0;
-      lim = l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l;
+      // (l <= 0: a dynamic header may have run past the end of the input -- neither the reference nor this
+      // kernel checks ReaderBitlenLeft inside it -- and then the first token must already report 2, LD:2428)
+      lim = l <= 0 ? 0u : (l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l);
       have = true;
     }
     // ---- every lane decodes the token starting `lane` bits ahead

@@ -22,52 +22,79 @@
 
 using namespace ldh;
 
+
 struct ldh_dict {
-  uint8_t *d_bytes;
-  size_t n;
-  uint32_t adler;
+  std::vector<uint8_t> bytes;  // host copy: every device a context runs on gets its own upload
+  uint32_t adler = 0;
+  std::mutex mu;
+  std::vector<std::pair<int, uint8_t *>> dev;  // (device, bytes + 64 zeros)
 };
 
 struct ldh_codec {
-  ldh::CodecTables *d_tab;  // device copy: header + npass suffix tables
-  uint32_t npass;
+  std::vector<uint8_t> img;  // host image of ldh::CodecTables: header + npass suffix tables
+  uint32_t npass = 0;
+  std::mutex mu;
+  std::vector<std::pair<int, ldh::CodecTables *>> dev;
 };
 
 namespace {
 
-std::mutex g_mu;
 thread_local std::string g_err;
-int g_device = -1;
-hipStream_t g_stream = nullptr;
 
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
 };
-// workspace (grow-only)
-DevBuf g_vbuf, g_prevd, g_bufA, g_bufB, g_bufC, g_sortA, g_sortB, g_blocks, g_adler, g_misc32a, g_misc32b;
-// staging for the host-pointer entry points
-DevBuf g_h_in, g_h_off, g_h_out, g_h_len, g_h_aux8, g_h_aux32a, g_h_aux32b, g_codec_tmp;
-
-// last compress batch (for ldh_debug_fetch)
-Batch g_last{};
-bool g_have_last = false;
-
-// profiler
-bool g_prof = false;
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+// one piece in flight of the host-pointer pipelines (see below)
+struct Slot {
+  PinBuf pin_in, pin_off, pin_out, pin_small;
+  DevBuf d_in, d_off, d_out, d_len, d_a8, d_a32a, d_a32b;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+  size_t w = 0;  // row width of the result copy in flight
+};
 struct ProfEntry {
   std::string name;
   double ms = 0;
   uint64_t launches = 0;
 };
-std::vector<ProfEntry> g_prof_entries;
 struct Pending {
   int idx;
   hipEvent_t a, b;
 };
-std::vector<Pending> g_pending;
-std::vector<hipEvent_t> g_event_pool;
-hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+
+// Everything the library owns on one GPU: streams, grow-only workspace, staging, profiler.  ldh_init(device) makes
+// one; ldh_init_devices() makes a pool of them (one per listed device; a device may be listed twice) over which the
+// host-pointer batch calls split their streams.  Calls on one context are serialised by its mutex.
+struct Ctx {
+  int device = -1;
+  std::mutex mu;
+  hipStream_t stream = nullptr, s_in = nullptr, s_out = nullptr;
+  // workspace (grow-only)
+  DevBuf vbuf, prevd, bufA, bufB, bufC, sortA, sortB, blocks, adler, misc32a, misc32b;
+  // staging for the host-pointer entry points
+  DevBuf h_in, h_off, h_out, h_len, h_aux8, h_aux32a, h_aux32b, codec_tmp;
+  Slot slot[3];
+  uint32_t *flags = nullptr;    // [0] streams longer than max_in_len since the last ldh_sync (k_plan)
+  bool attr_done = false;
+  // last compress batch (for ldh_debug_fetch)
+  Batch last{};
+  bool have_last = false;
+  // profiler
+  bool prof = false;
+  std::vector<ProfEntry> prof_entries;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+std::mutex g_mu;                 // guards the context tables below
+Ctx *g_default = nullptr;        // the context of ldh_init(device): what every call without a pool uses
+std::vector<Ctx *> g_pool;       // ldh_init_devices(): contexts the host-pointer batch calls are split over
+thread_local Ctx *t_cur = nullptr;  // ldh_use_context(): this thread's choice among the pool
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -83,6 +110,16 @@ int fail(int code, const char *fmt, ...) {
     hipError_t e_ = (expr);                                                                 \
     if (e_ != hipSuccess) return fail(LDH_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+Ctx *current() { return t_cur ? t_cur : g_default; }
+#define CTX_ENTER_ON(cx, ptr)                                                \
+  Ctx *cxp_ = (ptr);                                                         \
+  if (!cxp_) return fail(LDH_E_NOT_INIT, "ldh_init() has not been called"); \
+  Ctx &cx = *cxp_;                                                           \
+  std::lock_guard<std::mutex> lk(cx.mu);                                     \
+  HIPCHK(hipSetDevice(cx.device))
+// every entry point: CTX_ENTER(cx) -> Ctx &cx, locked, its device current in this thread
+#define CTX_ENTER(cx) CTX_ENTER_ON(cx, current())
 
 int ensure(DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return 0;
@@ -103,60 +140,61 @@ int ensure(DevBuf &b, size_t bytes) {
   return 0;
 }
 
-hipEvent_t get_event() {
-  if (!g_event_pool.empty()) {
-    hipEvent_t e = g_event_pool.back();
-    g_event_pool.pop_back();
+hipEvent_t get_event(Ctx &cx) {
+  if (!cx.event_pool.empty()) {
+    hipEvent_t e = cx.event_pool.back();
+    cx.event_pool.pop_back();
     return e;
   }
   hipEvent_t e;
   hipEventCreate(&e);
   return e;
 }
-int prof_index(const char *name) {
-  for (size_t i = 0; i < g_prof_entries.size(); i++)
-    if (g_prof_entries[i].name == name) return (int)i;
-  g_prof_entries.push_back({name, 0, 0});
-  return (int)g_prof_entries.size() - 1;
+int prof_index(Ctx &cx, const char *name) {
+  for (size_t i = 0; i < cx.prof_entries.size(); i++)
+    if (cx.prof_entries[i].name == name) return (int)i;
+  cx.prof_entries.push_back({name, 0, 0});
+  return (int)cx.prof_entries.size() - 1;
 }
-void prof_drain() {
-  if (g_pending.empty()) return;
-  hipStreamSynchronize(g_stream);
-  for (auto &p : g_pending) {
+void prof_drain(Ctx &cx) {
+  if (cx.pending.empty()) return;
+  hipStreamSynchronize(cx.stream);
+  for (auto &p : cx.pending) {
     float ms = 0;
     hipEventElapsedTime(&ms, p.a, p.b);
-    g_prof_entries[p.idx].ms += ms;
-    g_prof_entries[p.idx].launches++;
-    g_event_pool.push_back(p.a);
-    g_event_pool.push_back(p.b);
+    cx.prof_entries[p.idx].ms += ms;
+    cx.prof_entries[p.idx].launches++;
+    cx.event_pool.push_back(p.a);
+    cx.event_pool.push_back(p.b);
   }
-  g_pending.clear();
+  cx.pending.clear();
 }
 
 struct ProfScope {
+  Ctx &cx;
   int idx = -1;
   hipEvent_t a = nullptr;
-  explicit ProfScope(const char *name) {
-    if (g_prof) {
-      idx = prof_index(name);
-      a = get_event();
-      hipEventRecord(a, g_stream);
+  ProfScope(Ctx &c, const char *name) : cx(c) {
+    if (cx.prof) {
+      idx = prof_index(cx, name);
+      a = get_event(cx);
+      hipEventRecord(a, cx.stream);
     }
   }
   ~ProfScope() {
     if (idx >= 0) {
-      hipEvent_t b = get_event();
-      hipEventRecord(b, g_stream);
-      g_pending.push_back({idx, a, b});
-      if (g_pending.size() > 4096) prof_drain();
+      hipEvent_t b = get_event(cx);
+      hipEventRecord(b, cx.stream);
+      cx.pending.push_back({idx, a, b});
+      if (cx.pending.size() > 4096) prof_drain(cx);
     }
   }
 };
 
 #define LAUNCH(name, kern, grid, block, shmem, ...)                                   \
   do {                                                                                \
-    ProfScope ps_(name);                                                              \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, g_stream, __VA_ARGS__); \
+    ProfScope ps_(cx, name);                                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, cx.stream, __VA_ARGS__); \
   } while (0)
 
 size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -168,18 +206,41 @@ size_t workspace_budget() {
   return mb << 20;
 }
 
-bool g_attr_done = false;
-
-int check_init() {
-  if (g_device < 0) return fail(LDH_E_NOT_INIT, "ldh_init() has not been called");
-  return 0;
+// the device copy of a dictionary / codec on this context's GPU (uploaded on first use there)
+const uint8_t *dict_on(Ctx &cx, const ldh_dict *dc) {
+  ldh_dict *d = const_cast<ldh_dict *>(dc);
+  std::lock_guard<std::mutex> lk(d->mu);
+  for (auto &e : d->dev)
+    if (e.first == cx.device) return e.second;
+  uint8_t *p = nullptr;
+  const size_t n = d->bytes.size();
+  if (hipMalloc((void **)&p, n + 64) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, n + 64) != hipSuccess || hipMemcpy(p, d->bytes.data(), n, hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(p);
+    return nullptr;
+  }
+  d->dev.push_back({cx.device, p});
+  return p;
+}
+const ldh::CodecTables *codec_on(Ctx &cx, const ldh_codec *cc) {
+  ldh_codec *c = const_cast<ldh_codec *>(cc);
+  std::lock_guard<std::mutex> lk(c->mu);
+  for (auto &e : c->dev)
+    if (e.first == cx.device) return e.second;
+  ldh::CodecTables *p = nullptr;
+  if (hipMalloc((void **)&p, c->img.size()) != hipSuccess) return nullptr;
+  if (hipMemcpy(p, c->img.data(), c->img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(p);
+    return nullptr;
+  }
+  c->dev.push_back({cx.device, p});
+  return p;
 }
 
 // ---- compress ---------------------------------------------------------------
-int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
+int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
                         int fmt, int level, int strategy, const ldh_dict *dict, uint8_t *d_out,
                         size_t out_stride, uint32_t *d_out_len, uint8_t *d_pad_bits) {
-  if (int rc = check_init()) return rc;
   if (count == 0) return 0;
   if (level < 0 || level > 9) return fail(LDH_E_ARG, "level must be 0..9 for *_dev (got %d)", level);
   if (strategy < 0 || strategy > 3) return fail(LDH_E_ARG, "bad strategy %d", strategy);
@@ -189,7 +250,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   if (out_stride < ldh_compress_bound(max_in_len))
     return fail(LDH_E_CAPACITY, "out_stride %zu < ldh_compress_bound(%zu) = %zu", out_stride, max_in_len,
                 ldh_compress_bound(max_in_len));
-  const uint32_t dlen = dict ? (uint32_t)dict->n : 0;
+  const uint32_t dlen = dict ? (uint32_t)dict->bytes.size() : 0;
   const bool need_lz = level != 0 && strategy != LDH_STRATEGY_HUFFMAN_ONLY;
   // the dictionary only matters to the match search; keep V = input otherwise
   const uint32_t vd = need_lz ? dlen : 0;
@@ -207,26 +268,28 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
 
-  if (int rc = ensure(g_vbuf, chunk * (size_t)(nvp + kVPad) + 64)) return rc;
-  if (int rc = ensure(g_prevd, chunk * 2ull * nvp + 64)) return rc;
-  if (int rc = ensure(g_bufA, chunk * 4ull * nvp + 64)) return rc;
-  if (int rc = ensure(g_bufB, chunk * 4ull * nvp + 64)) return rc;
+  if (int rc = ensure(cx.vbuf, chunk * (size_t)(nvp + kVPad) + 64)) return rc;
+  if (int rc = ensure(cx.prevd, chunk * 2ull * nvp + 64)) return rc;
+  if (int rc = ensure(cx.bufA, chunk * 4ull * nvp + 64)) return rc;
+  if (int rc = ensure(cx.bufB, chunk * 4ull * nvp + 64)) return rc;
   if (greedy)
-    if (int rc = ensure(g_bufC, chunk * 8ull * nvp + 64)) return rc;
-  if (int rc = ensure(g_blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
-  if (int rc = ensure(g_adler, chunk * 4 + 64)) return rc;
+    if (int rc = ensure(cx.bufC, chunk * 8ull * nvp + 64)) return rc;
+  if (int rc = ensure(cx.blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
+  if (int rc = ensure(cx.adler, chunk * 4 + 64)) return rc;
   if (segs > 1) {
-    if (int rc = ensure(g_sortA, chunk * 4ull * segs * seg_stride + 64)) return rc;
-    if (int rc = ensure(g_sortB, chunk * 4ull * segs * seg_stride + 64)) return rc;
+    if (int rc = ensure(cx.sortA, chunk * 4ull * segs * seg_stride + 64)) return rc;
+    if (int rc = ensure(cx.sortB, chunk * 4ull * segs * seg_stride + 64)) return rc;
   }
 
-  if (!g_attr_done) {
+  const uint8_t *d_dict = nullptr;
+  if (dict && !(d_dict = dict_on(cx, dict))) return fail(LDH_E_NOMEM, "dictionary upload to device %d failed", cx.device);
+  if (!cx.attr_done) {
     HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true, kSortThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(kSortLdsMaxV)));
     for (const void *f : {(const void *)k_match_lazy<false, 1>, (const void *)k_match_lazy<true, 1>,
                           (const void *)k_match_lazy<false, kRefillMinDeep>, (const void *)k_match_lazy<true, kRefillMinDeep>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
-    g_attr_done = true;
+    cx.attr_done = true;
   }
 
   for (size_t s0 = 0; s0 < count; s0 += chunk) {
@@ -235,7 +298,7 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.in = d_in;
     B.in_off = d_in_off + s0;
     B.count = c;
-    B.dict = vd ? dict->d_bytes : nullptr;
+    B.dict = vd ? d_dict : nullptr;
     B.dlen = vd;
     B.dict_adler = dict ? dict->adler : 0;
     B.max_len = (uint32_t)max_in_len;
@@ -244,40 +307,41 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     B.level = level;
     B.strategy = strategy;
     B.fmt = fmt;
-    B.vbuf = (uint8_t *)g_vbuf.p;
-    B.prevd = (uint16_t *)g_prevd.p;
-    B.bufA = (uint32_t *)g_bufA.p;
-    B.bufB = (uint32_t *)g_bufB.p;
-    B.bufC = greedy ? (uint32_t *)g_bufC.p : nullptr;
+    B.vbuf = (uint8_t *)cx.vbuf.p;
+    B.prevd = (uint16_t *)cx.prevd.p;
+    B.bufA = (uint32_t *)cx.bufA.p;
+    B.bufB = (uint32_t *)cx.bufB.p;
+    B.bufC = greedy ? (uint32_t *)cx.bufC.p : nullptr;
     B.want_rank = greedy ? 1u : 0u;
     B.segs = segs;
-    B.sortA = segs > 1 ? (uint32_t *)g_sortA.p : B.bufA;
-    B.sortB = segs > 1 ? (uint32_t *)g_sortB.p : B.bufB;
+    B.sortA = segs > 1 ? (uint32_t *)cx.sortA.p : B.bufA;
+    B.sortB = segs > 1 ? (uint32_t *)cx.sortB.p : B.bufB;
     B.sort_stride = segs > 1 ? seg_stride : nvp;
     B.sort_lds = segs > 1 ? ((seg_stride + kVPad + 15) & ~15u) : (sort_in_lds ? ((nvp + kVPad + 15) & ~15u) : 0u);
     B.need_lz = need_lz ? 1u : 0u;
-    B.blocks = (BlockInfo *)g_blocks.p;
-    B.adler = (uint32_t *)g_adler.p;
+    B.blocks = (BlockInfo *)cx.blocks.p;
+    B.adler = (uint32_t *)cx.adler.p;
     B.out = d_out + s0 * out_stride;
     B.out_stride = out_stride;
     B.out_len = d_out_len + s0;
     B.pad_bits = d_pad_bits + s0;
+    B.too_long = cx.flags;
     // k_plan / k_bitpack read the zlib DICTID even when V carries no dictionary
     Batch Bz = B;
-    Bz.dict = dict ? dict->d_bytes : nullptr;
+    Bz.dict = d_dict;
 
     if (getenv("LDH_POISON")) {  // test hook: no kernel may depend on what a buffer held before
-      HIPCHK(hipMemsetAsync(g_vbuf.p, 0xA5, g_vbuf.cap, g_stream));
-      HIPCHK(hipMemsetAsync(g_prevd.p, 0xA5, g_prevd.cap, g_stream));
-      HIPCHK(hipMemsetAsync(g_bufA.p, 0xA5, g_bufA.cap, g_stream));
-      HIPCHK(hipMemsetAsync(g_bufB.p, 0xA5, g_bufB.cap, g_stream));
-      if (greedy) HIPCHK(hipMemsetAsync(g_bufC.p, 0xA5, g_bufC.cap, g_stream));
+      HIPCHK(hipMemsetAsync(cx.vbuf.p, 0xA5, cx.vbuf.cap, cx.stream));
+      HIPCHK(hipMemsetAsync(cx.prevd.p, 0xA5, cx.prevd.cap, cx.stream));
+      HIPCHK(hipMemsetAsync(cx.bufA.p, 0xA5, cx.bufA.cap, cx.stream));
+      HIPCHK(hipMemsetAsync(cx.bufB.p, 0xA5, cx.bufB.cap, cx.stream));
+      if (greedy) HIPCHK(hipMemsetAsync(cx.bufC.p, 0xA5, cx.bufC.cap, cx.stream));
       if (segs > 1) {
-        HIPCHK(hipMemsetAsync(g_sortA.p, 0xA5, g_sortA.cap, g_stream));
-        HIPCHK(hipMemsetAsync(g_sortB.p, 0xA5, g_sortB.cap, g_stream));
+        HIPCHK(hipMemsetAsync(cx.sortA.p, 0xA5, cx.sortA.cap, cx.stream));
+        HIPCHK(hipMemsetAsync(cx.sortB.p, 0xA5, cx.sortB.cap, cx.stream));
       }
-      HIPCHK(hipMemsetAsync(g_blocks.p, 0xA5, g_blocks.cap, g_stream));
-      HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, g_stream));
+      HIPCHK(hipMemsetAsync(cx.blocks.p, 0xA5, cx.blocks.cap, cx.stream));
+      HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, cx.stream));
     }
     // V (and, for the match search, the trigram chains)
     if (B.sort_lds && B.sort_lds <= kSortNarrowMaxLds)
@@ -308,23 +372,26 @@ int compress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, size_t co
     LAUNCH("k_plan", k_plan, (c + 63) / 64, 64, 0, Bz);
     LAUNCH("k_bitpack", k_bitpack, c * max_blocks, kPackThreads, 0, Bz);
     HIPCHK(hipGetLastError());
-    g_last = B;
-    g_have_last = true;
+    cx.last = B;
+    cx.have_last = true;
   }
   return 0;
 }
 
 // ---- decompress -------------------------------------------------------------
-int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                           size_t in_stride, size_t count, int fmt,
                           const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
                           uint32_t *d_bytes_left, int32_t *d_status) {
-  if (int rc = check_init()) return rc;
   if (count == 0) return 0;
   if (fmt != 0 && fmt != 1) return fail(LDH_E_ARG, "bad fmt %d", fmt);
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
-  if (int rc = ensure(g_misc32a, count * 4 + 64)) return rc;
-  if (int rc = ensure(g_misc32b, count * 4 + 64)) return rc;
+  // zlib trailer values read by k_inflate / Adler-32 sums of the results
+  if (int rc = ensure(cx.misc32a, count * 4 + 64)) return rc;
+  if (int rc = ensure(cx.misc32b, count * 4 + 64)) return rc;
+  uint32_t *expect = (uint32_t *)cx.misc32a.p, *actual = (uint32_t *)cx.misc32b.p;
+  const uint8_t *d_dict = nullptr;
+  if (dict && !(d_dict = dict_on(cx, dict))) return fail(LDH_E_NOMEM, "dictionary upload to device %d failed", cx.device);
   InflateArgs A{};
   A.in = d_in;
   A.in_off = d_in_off;
@@ -332,44 +399,44 @@ int decompress_dev_locked(const uint8_t *d_in, const uint64_t *d_in_off, const u
   A.in_stride = in_stride;
   A.count = (uint32_t)count;
   A.fmt = fmt;
-  A.dict = dict ? dict->d_bytes : nullptr;
-  A.dlen = dict ? (uint32_t)dict->n : 0;
+  A.dict = d_dict;
+  A.dlen = dict ? (uint32_t)dict->bytes.size() : 0;
   A.dict_adler = dict ? dict->adler : 0;
   A.out = d_out;
   A.out_stride = out_stride;
   A.out_len = d_out_len;
   A.bytes_left = d_bytes_left;
   A.status = d_status;
-  A.expect_adler = (uint32_t *)g_misc32a.p;
+  A.expect_adler = expect;
   LAUNCH("k_inflate", k_inflate, (uint32_t)count, kWave, 0, A);
   if (fmt == 1) {
     LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)d_out,
-           (const uint64_t *)nullptr, (uint64_t)out_stride, (const uint32_t *)d_out_len, (uint32_t *)g_misc32b.p);
+           (const uint64_t *)nullptr, (uint64_t)out_stride, (const uint32_t *)d_out_len, actual);
     LAUNCH("k_zlib_check", k_zlib_check, (uint32_t)((count + 255) / 256), 256, 0, (uint32_t)count,
-           (const uint32_t *)g_misc32a.p, (const uint32_t *)g_misc32b.p, d_status);
+           (const uint32_t *)expect, (const uint32_t *)actual, d_status);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 // host staging helpers ---------------------------------------------------------
-int upload_inputs(const uint8_t *in_base, const uint64_t *in_off, size_t count) {
+int upload_inputs(Ctx &cx, const uint8_t *in_base, const uint64_t *in_off, size_t count) {
   const uint64_t total = in_off[count];
-  if (int rc = ensure(g_h_in, total + 64)) return rc;
-  if (int rc = ensure(g_h_off, (count + 1) * 8)) return rc;
+  if (int rc = ensure(cx.h_in, total + 64)) return rc;
+  if (int rc = ensure(cx.h_off, (count + 1) * 8)) return rc;
   // offsets are re-based to start at 0 so that the device copy of the data is aligned
   std::vector<uint64_t> off(count + 1);
   for (size_t i = 0; i <= count; i++) off[i] = in_off[i] - in_off[0];
   if (total - in_off[0])
-    HIPCHK(hipMemcpyAsync(g_h_in.p, in_base + in_off[0], total - in_off[0], hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(g_h_off.p, off.data(), (count + 1) * 8, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));  // `off` goes out of scope
+    HIPCHK(hipMemcpyAsync(cx.h_in.p, in_base + in_off[0], total - in_off[0], hipMemcpyHostToDevice, cx.stream));
+  HIPCHK(hipMemcpyAsync(cx.h_off.p, off.data(), (count + 1) * 8, hipMemcpyHostToDevice, cx.stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));  // `off` goes out of scope
   return 0;
 }
 
 // ---- host-pointer batches: pinned staging, copies overlapped with kernels -----
 // A batch is cut into pieces of about piece_bytes() (64 MiB).  Piece k is gathered into pinned memory by
-// a few host threads, copied in on one stream, processed on g_stream, and its results are
+// a few host threads, copied in on one stream, processed on cx.stream, and its results are
 // copied out (only the bytes produced: a 2D copy as wide as the piece's longest result) on a
 // third stream and scattered to the caller's slots by the host threads -- while the kernels
 // of piece k+1 run.  Compression alternates two slots; decompression, whose results are the
@@ -384,19 +451,6 @@ size_t piece_bytes() {
 // k_inflate runs one wavefront per stream and a stream takes milliseconds however few there are,
 // so decompression wants thousands of streams per piece
 size_t inflate_piece_bytes() { return 4 * piece_bytes(); }
-struct PinBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-};
-struct Slot {
-  PinBuf pin_in, pin_off, pin_out, pin_small;
-  DevBuf d_in, d_off, d_out, d_len, d_a8, d_a32a, d_a32b;
-  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
-  size_t w = 0;  // row width of the result copy in flight
-};
-Slot g_slot[3];
-hipStream_t g_s_in = nullptr, g_s_out = nullptr;
-
 int ensure_pinned(PinBuf &b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
@@ -412,11 +466,11 @@ int ensure_pinned(PinBuf &b, size_t bytes) {
   return 0;
 }
 
-int pipeline_init() {
-  if (g_s_in) return 0;
-  HIPCHK(hipStreamCreateWithFlags(&g_s_in, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&g_s_out, hipStreamNonBlocking));
-  for (Slot &sl : g_slot) {
+int pipeline_init(Ctx &cx) {
+  if (cx.s_in) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&cx.s_in, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&cx.s_out, hipStreamNonBlocking));
+  for (Slot &sl : cx.slot) {
     HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
@@ -424,8 +478,8 @@ int pipeline_init() {
   return 0;
 }
 
-void pipeline_free() {
-  for (Slot &sl : g_slot) {
+void pipeline_free(Ctx &cx) {
+  for (Slot &sl : cx.slot) {
     for (PinBuf *b : {&sl.pin_in, &sl.pin_off, &sl.pin_out, &sl.pin_small}) {
       if (b->p) hipHostFree(b->p);
       b->p = nullptr;
@@ -441,9 +495,9 @@ void pipeline_free() {
     if (sl.ev_out) hipEventDestroy(sl.ev_out);
     sl.ev_in = sl.ev_done = sl.ev_out = nullptr;
   }
-  if (g_s_in) hipStreamDestroy(g_s_in);
-  if (g_s_out) hipStreamDestroy(g_s_out);
-  g_s_in = g_s_out = nullptr;
+  if (cx.s_in) hipStreamDestroy(cx.s_in);
+  if (cx.s_out) hipStreamDestroy(cx.s_out);
+  cx.s_in = cx.s_out = nullptr;
 }
 
 // an entry point that returns early (an error) must not leave copies or kernels in flight on
@@ -493,37 +547,138 @@ void par_memcpy(void *dst, const void *src, size_t bytes) {
 // =============================================================================
 extern "C" {
 
-int ldh_init(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_device == device && g_stream) return 0;
+namespace {
+Ctx *ctx_create(int device) {  // g_mu held
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) return fail(LDH_E_HIP, "no HIP device: %s", hipGetErrorString(e));
-  if (device < 0 || device >= n) return fail(LDH_E_ARG, "device %d out of range (count %d)", device, n);
-  HIPCHK(hipSetDevice(device));
-  if (g_stream && g_device != device) return fail(LDH_E_ARG, "already initialised on device %d", g_device);
-  HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreate(&g_t0));
-  HIPCHK(hipEventCreate(&g_t1));
-  g_device = device;
+  if (e != hipSuccess || n <= 0) {
+    fail(LDH_E_HIP, "no HIP device: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    fail(LDH_E_ARG, "device %d out of range (count %d)", device, n);
+    return nullptr;
+  }
+  Ctx *c = new Ctx;
+  c->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
+      (e = hipMalloc((void **)&c->flags, 256)) != hipSuccess || (e = hipMemset(c->flags, 0, 256)) != hipSuccess) {
+    fail(LDH_E_HIP, "context on device %d: %s", device, hipGetErrorString(e));
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+void ctx_destroy(Ctx *c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  Ctx &cx = *c;
+  pipeline_free(cx);
+  for (DevBuf *b : {&cx.vbuf, &cx.prevd, &cx.bufA, &cx.bufB, &cx.bufC, &cx.sortA, &cx.sortB, &cx.blocks, &cx.adler, &cx.misc32a, &cx.misc32b, &cx.h_in,
+                    &cx.h_off, &cx.h_out, &cx.h_len, &cx.h_aux8, &cx.h_aux32a, &cx.h_aux32b, &cx.codec_tmp}) {
+    if (b->p) hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  for (auto &p : cx.pending) {
+    hipEventDestroy(p.a);
+    hipEventDestroy(p.b);
+  }
+  for (hipEvent_t e : cx.event_pool) hipEventDestroy(e);
+  if (cx.flags) hipFree(cx.flags);
+  hipEventDestroy(cx.t0);
+  hipEventDestroy(cx.t1);
+  hipStreamDestroy(cx.stream);
+}
+}  // namespace
+
+int ldh_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_default) {
+    if (g_default->device == device) return 0;
+    return fail(LDH_E_ARG, "already initialised on device %d (ldh_init_devices() drives several)", g_default->device);
+  }
+  for (Ctx *c : g_pool)  // ldh_init_devices() came first: its first context on this device is the default
+    if (c->device == device) {
+      g_default = c;
+      return 0;
+    }
+  Ctx *c = ctx_create(device);
+  if (!c) return LDH_E_HIP;
+  g_default = c;
+  return 0;
+}
+
+int ldh_init_devices(const int *devices, int n) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_pool.empty()) return fail(LDH_E_ARG, "ldh_init_devices() was already called (%zu contexts)", g_pool.size());
+  std::vector<int> list;
+  if (devices && n > 0) {
+    list.assign(devices, devices + n);
+  } else {
+    const int cnt = ldh_device_count();
+    if (cnt <= 0) return fail(LDH_E_HIP, "no HIP device");
+    for (int d = 0; d < cnt; d++) list.push_back(d);
+  }
+  std::vector<Ctx *> made;
+  bool default_used = false;
+  for (int d : list) {
+    Ctx *c = nullptr;
+    if (g_default && g_default->device == d && !default_used) {
+      c = g_default;
+      default_used = true;
+    } else {
+      c = ctx_create(d);
+      if (!c) {
+        for (Ctx *m : made)
+          if (m != g_default) {
+            ctx_destroy(m);
+            delete m;
+          }
+        return LDH_E_HIP;
+      }
+    }
+    made.push_back(c);
+  }
+  g_pool = made;
+  if (!g_default) g_default = g_pool[0];
+  return 0;
+}
+
+int ldh_pool_size(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return (int)g_pool.size();
+}
+
+int ldh_use_context(int index) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (index < 0) {
+    t_cur = nullptr;
+    return 0;
+  }
+  if ((size_t)index >= g_pool.size()) return fail(LDH_E_ARG, "context %d out of range (pool of %zu)", index, g_pool.size());
+  t_cur = g_pool[index];
   return 0;
 }
 
 void ldh_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_device < 0) return;
-  hipDeviceSynchronize();
-  pipeline_free();
-  for (DevBuf *b : {&g_vbuf, &g_prevd, &g_bufA, &g_bufB, &g_bufC, &g_sortA, &g_sortB, &g_blocks, &g_adler, &g_misc32a, &g_misc32b, &g_h_in,
-                    &g_h_off, &g_h_out, &g_h_len, &g_h_aux8, &g_h_aux32a, &g_h_aux32b, &g_codec_tmp}) {
-    if (b->p) hipFree(b->p);
-    b->p = nullptr;
-    b->cap = 0;
+  bool default_in_pool = false;
+  for (Ctx *c : g_pool) {
+    default_in_pool = default_in_pool || c == g_default;
+    ctx_destroy(c);
+    delete c;
   }
-  g_have_last = false;
-  hipStreamDestroy(g_stream);
-  g_stream = nullptr;
-  g_device = -1;
+  g_pool.clear();
+  if (g_default && !default_in_pool) {
+    ctx_destroy(g_default);
+    delete g_default;
+  }
+  g_default = nullptr;
+  t_cur = nullptr;  // (other threads' choices dangle: shut down only when no other thread uses the library)
 }
 
 int ldh_device_count(void) {
@@ -533,11 +688,20 @@ int ldh_device_count(void) {
 }
 
 const char *ldh_last_error(void) { return g_err.c_str(); }
-void *ldh_stream(void) { return (void *)g_stream; }
+void *ldh_stream(void) {
+  Ctx *c = current();
+  return c ? (void *)c->stream : nullptr;
+}
 int ldh_sync(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
-  HIPCHK(hipStreamSynchronize(g_stream));
+  CTX_ENTER(cx);
+  HIPCHK(hipStreamSynchronize(cx.stream));
+  // streams a *_dev compress call found longer than its max_in_len (k_plan counts them; their out_len is 0)
+  uint32_t too_long = 0;
+  HIPCHK(hipMemcpy(&too_long, cx.flags, 4, hipMemcpyDeviceToHost));
+  if (too_long) {
+    HIPCHK(hipMemset(cx.flags, 0, 4));
+    return fail(LDH_E_TOO_LONG, "%u stream(s) longer than max_in_len were not compressed (out_len 0)", too_long);
+  }
   return 0;
 }
 
@@ -548,37 +712,66 @@ size_t ldh_compress_bound(size_t n) {
   return round_up(n + n / 4 + 512 * nblocks + 64, 16);
 }
 
+// Contiguous ranges of a batch balanced by bytes: part p takes streams [first[p], first[p+1]).
+// Pure host arithmetic (tested without a GPU).
+int ldh_partition_by_bytes(const uint64_t *in_off, size_t count, int parts, size_t *first) {
+  if (!in_off || !first || parts <= 0) return fail(LDH_E_ARG, "ldh_partition_by_bytes: bad arguments");
+  const uint64_t base = in_off[0], total = in_off[count] - base;
+  first[0] = 0;
+  size_t s = 0;
+  for (int p = 1; p < parts; p++) {
+    // the boundary of part p is the first stream that starts at or beyond p/parts of the bytes (streams are
+    // whole; an empty batch or zero-length streams go to the earliest part that can take them)
+    const uint64_t target = (uint64_t)((__uint128_t)total * (uint64_t)p / (uint64_t)parts);
+    while (s < count && in_off[s] - base < target) s++;
+    // spread streams evenly when bytes do not separate them (all empty, or fewer bytes than parts)
+    first[p] = s;
+  }
+  first[parts] = count;
+  if (total == 0)
+    for (int p = 1; p < parts; p++) first[p] = count * (size_t)p / (size_t)parts;
+  return 0;
+}
+
 ldh_dict *ldh_dict_create(const uint8_t *bytes, size_t n) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (check_init()) return nullptr;
+  Ctx *cxp = current();
+  if (!cxp) {
+    fail(LDH_E_NOT_INIT, "ldh_init() has not been called");
+    return nullptr;
+  }
+  Ctx &cx = *cxp;
+  std::lock_guard<std::mutex> lk(cx.mu);
   if (!bytes || n == 0 || n > 32768) {  // LD:513-521
     fail(LDH_E_ARG, "dictionary length must be 1..32768 (got %zu)", n);
     return nullptr;
   }
-  ldh_dict *d = new ldh_dict{nullptr, n, 0};
-  if (hipMalloc((void **)&d->d_bytes, n + 64) != hipSuccess) {
+  if (hipSetDevice(cx.device) != hipSuccess) {
+    fail(LDH_E_HIP, "hipSetDevice(%d)", cx.device);
+    return nullptr;
+  }
+  ldh_dict *d = new ldh_dict;
+  d->bytes.assign(bytes, bytes + n);
+  const uint8_t *d_bytes = dict_on(cx, d);
+  if (!d_bytes) {
     delete d;
     fail(LDH_E_NOMEM, "hipMalloc dict");
     return nullptr;
   }
-  hipMemsetAsync(d->d_bytes, 0, n + 64, g_stream);
-  hipMemcpyAsync(d->d_bytes, bytes, n, hipMemcpyHostToDevice, g_stream);
   // Adler-32 of the dictionary through the device kernel (LD:522)
   uint64_t off[2] = {0, n};
   uint64_t *d_off = nullptr;
   uint32_t *d_ad = nullptr;
   hipMalloc((void **)&d_off, 16);
   hipMalloc((void **)&d_ad, 4);
-  hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, g_stream);
-  hipLaunchKernelGGL(k_adler32, dim3(1), dim3(kAdlerThreads), 0, g_stream, (const uint8_t *)d->d_bytes,
+  hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, cx.stream);
+  hipLaunchKernelGGL(k_adler32, dim3(1), dim3(kAdlerThreads), 0, cx.stream, d_bytes,
                      (const uint64_t *)d_off, (uint64_t)0, (const uint32_t *)nullptr, d_ad);
-  hipMemcpyAsync(&d->adler, d_ad, 4, hipMemcpyDeviceToHost, g_stream);
-  hipError_t e = hipStreamSynchronize(g_stream);
+  hipMemcpyAsync(&d->adler, d_ad, 4, hipMemcpyDeviceToHost, cx.stream);
+  hipError_t e = hipStreamSynchronize(cx.stream);
   hipFree(d_off);
   hipFree(d_ad);
   if (e != hipSuccess) {
-    hipFree(d->d_bytes);
-    delete d;
+    ldh_dict_free(d);
     fail(LDH_E_HIP, "dict upload: %s", hipGetErrorString(e));
     return nullptr;
   }
@@ -586,43 +779,44 @@ ldh_dict *ldh_dict_create(const uint8_t *bytes, size_t n) {
 }
 void ldh_dict_free(ldh_dict *d) {
   if (!d) return;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_stream) hipStreamSynchronize(g_stream);
-  hipFree(d->d_bytes);
+  for (auto &e : d->dev) {  // (work that still reads a copy must have been synchronised by the caller)
+    hipSetDevice(e.first);
+    hipDeviceSynchronize();
+    hipFree(e.second);
+  }
   delete d;
 }
 uint32_t ldh_dict_adler32(const ldh_dict *d) { return d ? d->adler : 0; }
-size_t ldh_dict_len(const ldh_dict *d) { return d ? d->n : 0; }
+size_t ldh_dict_len(const ldh_dict *d) { return d ? d->bytes.size() : 0; }
 
 // ---- batched, device pointers -------------------------------------------------
 int ldh_compress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
                            int fmt, int level, int strategy, const ldh_dict *dict, uint8_t *d_out,
                            size_t out_stride, uint32_t *d_out_len, uint8_t *d_pad_bits) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  return compress_dev_locked(d_in, d_in_off, count, max_in_len, fmt, level, strategy, dict, d_out, out_stride,
+  CTX_ENTER(cx);
+  return compress_dev_locked(cx, d_in, d_in_off, count, max_in_len, fmt, level, strategy, dict, d_out, out_stride,
                              d_out_len, d_pad_bits);
 }
 
 int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, int fmt,
                              const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
                              uint32_t *d_bytes_left, int32_t *d_status) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  return decompress_dev_locked(d_in, d_in_off, nullptr, 0, count, fmt, dict, d_out, out_stride, d_out_len,
+  CTX_ENTER(cx);
+  return decompress_dev_locked(cx, d_in, d_in_off, nullptr, 0, count, fmt, dict, d_out, out_stride, d_out_len,
                                d_bytes_left, d_status);
 }
 
 int ldh_decompress_slots_dev(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_len, size_t count,
                              int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
                              uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CTX_ENTER(cx);
   if (!d_in_len) return fail(LDH_E_ARG, "d_in_len is required");
-  return decompress_dev_locked(d_in, nullptr, d_in_len, in_stride, count, fmt, dict, d_out, out_stride, d_out_len,
+  return decompress_dev_locked(cx, d_in, nullptr, d_in_len, in_stride, count, fmt, dict, d_out, out_stride, d_out_len,
                                d_bytes_left, d_status);
 }
 
 int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint32_t *d_adler) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!count) return 0;
   LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, d_in, d_in_off, (uint64_t)0,
          (const uint32_t *)nullptr, d_adler);
@@ -632,8 +826,7 @@ int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t 
 
 int ldh_print6_encode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint8_t *d_out,
                                 size_t out_stride, uint32_t *d_out_len) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   LAUNCH("k_print6_encode", k_print6_encode, (uint32_t)count, kP6Threads, 0, d_in, d_in_off, d_out,
@@ -644,8 +837,7 @@ int ldh_print6_encode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, s
 
 int ldh_print6_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint8_t *d_out,
                                 size_t out_stride, uint32_t *d_out_len, uint8_t *d_ok) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!count) return 0;
   LAUNCH("k_print6_decode", k_print6_decode, (uint32_t)count, kP6Threads, 0, d_in, d_in_off, d_out,
          (uint64_t)out_stride, d_out_len, d_ok);
@@ -654,15 +846,14 @@ int ldh_print6_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, s
 }
 
 // ---- batched, host pointers ---------------------------------------------------
-int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt, int level,
-                       int strategy, const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
-                       uint32_t *out_len, uint8_t *pad_bits) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt, int level,
+                             int strategy, const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
+                             uint32_t *out_len, uint8_t *pad_bits) {
+  CTX_ENTER_ON(cx, on);
   if (count == 0) return 0;
   if (level < -1 || level > 9) return fail(LDH_E_ARG, "level must be -1..9 (got %d)", level);
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
-  if (int rc = pipeline_init()) return rc;
+  if (int rc = pipeline_init(cx)) return rc;
   DrainGuard drain;
   // group streams by resolved level (LD:1782-1790) and by size class so that the
   // per-stream workspace (sized by the longest stream of a launch) is not wasted
@@ -710,7 +901,7 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
       i = pc.last;
     }
     auto finish = [&](size_t k) -> int {  // results of piece k to the caller
-      Slot &sl = g_slot[k & 1];
+      Slot &sl = cx.slot[k & 1];
       const Piece &pc = pieces[k];
       const size_t gc = pc.last - pc.first;
       HIPCHK(hipEventSynchronize(sl.ev_done));
@@ -721,8 +912,8 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
       w = std::min(round_up(w, 16), out_stride);
       if (int rc = ensure_pinned(sl.pin_out, gc * w + 64)) return rc;
       if (w) {
-        HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, g_s_out));
-        HIPCHK(hipStreamSynchronize(g_s_out));
+        HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, cx.s_out));
+        HIPCHK(hipStreamSynchronize(cx.s_out));
       }
       const uint8_t *rows = (const uint8_t *)sl.pin_out.p;
       const size_t *idx = g.idx.data() + pc.first;
@@ -736,7 +927,7 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
       return 0;
     };
     for (size_t k = 0; k < pieces.size(); k++) {
-      Slot &sl = g_slot[k & 1];
+      Slot &sl = cx.slot[k & 1];
       const Piece &pc = pieces[k];
       const size_t gc = pc.last - pc.first;
       // (piece k-2, the last user of this slot, was finished before piece k-1 was enqueued)
@@ -767,17 +958,17 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
           for (size_t i = lo; i < hi; i++) memcpy(dst + off[i], in_base + in_off[idx[i]], off[i + 1] - off[i]);
         });
       }
-      if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, g_s_in));
-      HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, g_s_in));
-      HIPCHK(hipEventRecord(sl.ev_in, g_s_in));
-      HIPCHK(hipStreamWaitEvent(g_stream, sl.ev_in, 0));
-      if (int rc = compress_dev_locked((const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, gc, max_len, fmt, lv,
+      if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, cx.s_in));
+      HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, cx.s_in));
+      HIPCHK(hipEventRecord(sl.ev_in, cx.s_in));
+      HIPCHK(hipStreamWaitEvent(cx.stream, sl.ev_in, 0));
+      if (int rc = compress_dev_locked(cx, (const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, gc, max_len, fmt, lv,
                                        strategy, dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
                                        (uint8_t *)sl.d_a8.p))
         return rc;
-      HIPCHK(hipMemcpyAsync(sl.pin_small.p, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
-      HIPCHK(hipMemcpyAsync((uint8_t *)sl.pin_small.p + gc * 4, sl.d_a8.p, gc, hipMemcpyDeviceToHost, g_stream));
-      HIPCHK(hipEventRecord(sl.ev_done, g_stream));
+      HIPCHK(hipMemcpyAsync(sl.pin_small.p, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
+      HIPCHK(hipMemcpyAsync((uint8_t *)sl.pin_small.p + gc * 4, sl.d_a8.p, gc, hipMemcpyDeviceToHost, cx.stream));
+      HIPCHK(hipEventRecord(sl.ev_done, cx.stream));
       if (k > 0)
         if (int rc = finish(k - 1)) return rc;
     }
@@ -787,14 +978,13 @@ int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t co
   return 0;
 }
 
-int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
-                         const ldh_dict *dict, uint8_t *out_base, size_t out_stride, uint32_t *out_len,
-                         uint32_t *bytes_left, int32_t *status) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
+                               const ldh_dict *dict, uint8_t *out_base, size_t out_stride, uint32_t *out_len,
+                               uint32_t *bytes_left, int32_t *status) {
+  CTX_ENTER_ON(cx, on);
   if (count == 0) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
-  if (int rc = pipeline_init()) return rc;
+  if (int rc = pipeline_init(cx)) return rc;
   DrainGuard drain;
   struct Piece {
     size_t first, last;
@@ -808,7 +998,7 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
     i = j;
   }
   auto start_out = [&](size_t k) -> int {  // piece k is done on the device: start copying its results out
-    Slot &sl = g_slot[k % 3];
+    Slot &sl = cx.slot[k % 3];
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first;
     HIPCHK(hipEventSynchronize(sl.ev_done));
@@ -825,14 +1015,14 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
     if (!w) return 0;
     if (int rc = ensure_pinned(sl.pin_out, gc * w + 64)) return rc;
     if (w == out_stride)
-      HIPCHK(hipMemcpyAsync(sl.pin_out.p, sl.d_out.p, gc * w, hipMemcpyDeviceToHost, g_s_out));
+      HIPCHK(hipMemcpyAsync(sl.pin_out.p, sl.d_out.p, gc * w, hipMemcpyDeviceToHost, cx.s_out));
     else
-      HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, g_s_out));
-    HIPCHK(hipEventRecord(sl.ev_out, g_s_out));
+      HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, cx.s_out));
+    HIPCHK(hipEventRecord(sl.ev_out, cx.s_out));
     return 0;
   };
   auto scatter = [&](size_t k) -> int {  // results of piece k from pinned memory to the caller's slots
-    Slot &sl = g_slot[k % 3];
+    Slot &sl = cx.slot[k % 3];
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first, w = sl.w;
     if (!w) return 0;
@@ -848,7 +1038,7 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
     return 0;
   };
   for (size_t k = 0; k < pieces.size(); k++) {
-    Slot &sl = g_slot[k % 3];  // (its last user, piece k-3, was scattered before piece k-1 was enqueued)
+    Slot &sl = cx.slot[k % 3];  // (its last user, piece k-3, was scattered before piece k-1 was enqueued)
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first;
     const uint64_t base = in_off[pc.first], tot = in_off[pc.last] - base;
@@ -865,19 +1055,19 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
     uint64_t *off = (uint64_t *)sl.pin_off.p;
     for (size_t i = 0; i <= gc; i++) off[i] = in_off[pc.first + i] - base;
     par_memcpy(sl.pin_in.p, in_base + base, tot);
-    if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, g_s_in));
-    HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, g_s_in));
-    HIPCHK(hipEventRecord(sl.ev_in, g_s_in));
-    HIPCHK(hipStreamWaitEvent(g_stream, sl.ev_in, 0));
-    if (int rc = decompress_dev_locked((const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, nullptr, 0, gc, fmt,
+    if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, cx.s_in));
+    HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, cx.s_in));
+    HIPCHK(hipEventRecord(sl.ev_in, cx.s_in));
+    HIPCHK(hipStreamWaitEvent(cx.stream, sl.ev_in, 0));
+    if (int rc = decompress_dev_locked(cx, (const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, nullptr, 0, gc, fmt,
                                        dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
                                        (uint32_t *)sl.d_a32a.p, (int32_t *)sl.d_a32b.p))
       return rc;
     uint8_t *small = (uint8_t *)sl.pin_small.p;
-    HIPCHK(hipMemcpyAsync(small, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipMemcpyAsync(small + gc * 4, sl.d_a32a.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipMemcpyAsync(small + gc * 8, sl.d_a32b.p, gc * 4, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipEventRecord(sl.ev_done, g_stream));
+    HIPCHK(hipMemcpyAsync(small, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
+    HIPCHK(hipMemcpyAsync(small + gc * 4, sl.d_a32a.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
+    HIPCHK(hipMemcpyAsync(small + gc * 8, sl.d_a32b.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
+    HIPCHK(hipEventRecord(sl.ev_done, cx.stream));
     if (k > 0)
       if (int rc = start_out(k - 1)) return rc;
     if (k > 1)
@@ -892,61 +1082,107 @@ int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t 
   return 0;
 }
 
-int ldh_adler32_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint32_t *adler) {
+// The contexts a host-pointer batch call runs on: the pool of ldh_init_devices() (unless this thread chose one
+// of them with ldh_use_context), else the one default context.
+static std::vector<Ctx *> batch_contexts() {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  if (t_cur || g_pool.size() < 2) return {t_cur ? t_cur : g_default};
+  return g_pool;
+}
+// f(context, first, last) for the byte-balanced contiguous part of the batch each context takes (host-side
+// scatter, one host thread per context, no inter-GPU exchange; results land in the caller's one buffer)
+extern "C++" template <class F>
+static int over_contexts(const uint64_t *in_off, size_t count, F f) {
+  const std::vector<Ctx *> cxs = batch_contexts();
+  if (cxs.size() < 2 || count < 2) return f(cxs[0], (size_t)0, count);
+  const int P = (int)cxs.size();
+  std::vector<size_t> first(P + 1);
+  if (int rc = ldh_partition_by_bytes(in_off, count, P, first.data())) return rc;
+  std::vector<int> rcs(P, 0);
+  std::vector<std::string> errs(P);
+  std::vector<std::thread> th;
+  for (int p = 0; p < P; p++)
+    th.emplace_back([&, p] {
+      if (first[p + 1] == first[p]) return;
+      rcs[p] = f(cxs[p], first[p], first[p + 1]);
+      if (rcs[p]) errs[p] = g_err;  // (thread-local: hand it to the caller's thread)
+    });
+  for (auto &t : th) t.join();
+  for (int p = 0; p < P; p++)
+    if (rcs[p]) return fail(rcs[p], "context %d (device %d): %s", p, cxs[p]->device, errs[p].c_str());
+  return 0;
+}
+
+int ldh_compress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt, int level,
+                       int strategy, const ldh_dict *dict, uint8_t *out_base, size_t out_stride,
+                       uint32_t *out_len, uint8_t *pad_bits) {
+  return over_contexts(in_off, count, [=](Ctx *c, size_t a, size_t b) {
+    return compress_batch_on(c, in_base, in_off + a, b - a, fmt, level, strategy, dict, out_base + a * out_stride,
+                             out_stride, out_len + a, pad_bits + a);
+  });
+}
+
+int ldh_decompress_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, int fmt,
+                         const ldh_dict *dict, uint8_t *out_base, size_t out_stride, uint32_t *out_len,
+                         uint32_t *bytes_left, int32_t *status) {
+  return over_contexts(in_off, count, [=](Ctx *c, size_t a, size_t b) {
+    return decompress_batch_on(c, in_base, in_off + a, b - a, fmt, dict, out_base + a * out_stride, out_stride,
+                               out_len + a, bytes_left + a, status + a);
+  });
+}
+
+int ldh_adler32_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint32_t *adler) {
+  CTX_ENTER(cx);
   if (!count) return 0;
-  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
-  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
-  LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)g_h_in.p,
-         (const uint64_t *)g_h_off.p, (uint64_t)0, (const uint32_t *)nullptr, (uint32_t *)g_h_len.p);
-  HIPCHK(hipMemcpyAsync(adler, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  if (int rc = upload_inputs(cx, in_base, in_off, count)) return rc;
+  if (int rc = ensure(cx.h_len, count * 4 + 64)) return rc;
+  LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)cx.h_in.p,
+         (const uint64_t *)cx.h_off.p, (uint64_t)0, (const uint32_t *)nullptr, (uint32_t *)cx.h_len.p);
+  HIPCHK(hipMemcpyAsync(adler, cx.h_len.p, count * 4, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));
   return 0;
 }
 
 int ldh_print6_encode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint8_t *out_base,
                             size_t out_stride, uint32_t *out_len) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   for (size_t s = 0; s < count; s++)
     if (((in_off[s + 1] - in_off[s]) * 8 + 5) / 6 > out_stride)
       return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
-  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
-  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
-  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
-  LAUNCH("k_print6_encode", k_print6_encode, (uint32_t)count, kP6Threads, 0, (const uint8_t *)g_h_in.p,
-         (const uint64_t *)g_h_off.p, (uint8_t *)g_h_out.p, (uint64_t)out_stride, (uint32_t *)g_h_len.p);
-  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
-                          g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  if (int rc = upload_inputs(cx, in_base, in_off, count)) return rc;
+  if (int rc = ensure(cx.h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(cx.h_len, count * 4 + 64)) return rc;
+  LAUNCH("k_print6_encode", k_print6_encode, (uint32_t)count, kP6Threads, 0, (const uint8_t *)cx.h_in.p,
+         (const uint64_t *)cx.h_off.p, (uint8_t *)cx.h_out.p, (uint64_t)out_stride, (uint32_t *)cx.h_len.p);
+  HIPCHK(hipMemcpyAsync(out_len, cx.h_len.p, count * 4, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, cx.h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          cx.stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));
   return 0;
 }
 
 int ldh_print6_decode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint8_t *out_base,
                             size_t out_stride, uint32_t *out_len, uint8_t *ok) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   for (size_t s = 0; s < count; s++)
     if ((in_off[s + 1] - in_off[s]) * 3 / 4 + 3 > out_stride)
       return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
-  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
-  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
-  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
-  if (int rc = ensure(g_h_aux8, count + 64)) return rc;
-  LAUNCH("k_print6_decode", k_print6_decode, (uint32_t)count, kP6Threads, 0, (const uint8_t *)g_h_in.p,
-         (const uint64_t *)g_h_off.p, (uint8_t *)g_h_out.p, (uint64_t)out_stride, (uint32_t *)g_h_len.p,
-         (uint8_t *)g_h_aux8.p);
-  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(ok, g_h_aux8.p, count, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
-                          g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  if (int rc = upload_inputs(cx, in_base, in_off, count)) return rc;
+  if (int rc = ensure(cx.h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(cx.h_len, count * 4 + 64)) return rc;
+  if (int rc = ensure(cx.h_aux8, count + 64)) return rc;
+  LAUNCH("k_print6_decode", k_print6_decode, (uint32_t)count, kP6Threads, 0, (const uint8_t *)cx.h_in.p,
+         (const uint64_t *)cx.h_off.p, (uint8_t *)cx.h_out.p, (uint64_t)out_stride, (uint32_t *)cx.h_len.p,
+         (uint8_t *)cx.h_aux8.p);
+  HIPCHK(hipMemcpyAsync(out_len, cx.h_len.p, count * 4, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipMemcpyAsync(ok, cx.h_aux8.p, count, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, cx.h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          cx.stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));
   return 0;
 }
 
@@ -1061,41 +1297,48 @@ ldh_codec *ldh_codec_create(const uint8_t *reserved, size_t nr, const uint8_t *e
   }
   H.npass = (uint32_t)passes.size();
 
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (check_init()) { *err = "libdeflate_hip is not initialised"; return nullptr; }
+  Ctx *cxp = current();
+  if (!cxp) { *err = "libdeflate_hip is not initialised"; return nullptr; }
   const size_t head = offsetof(ldh::CodecTables, pass_dec);
   const size_t bytes = head + passes.size() * 512;
-  std::vector<uint8_t> img(bytes);
-  memcpy(img.data(), &H, head);
-  for (size_t k = 0; k < passes.size(); k++) memcpy(img.data() + head + k * 512, passes[k].data(), 512);
-  ldh_codec *c = new ldh_codec{nullptr, H.npass};
-  if (hipMalloc((void **)&c->d_tab, bytes) != hipSuccess ||
-      hipMemcpy(c->d_tab, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
-    if (c->d_tab) hipFree(c->d_tab);
-    delete c;
-    *err = "hipMalloc/hipMemcpy of the codec tables failed";
-    fail(LDH_E_NOMEM, "%s", *err);
-    return nullptr;
+  ldh_codec *c = new ldh_codec;
+  c->npass = H.npass;
+  c->img.resize(bytes);
+  memcpy(c->img.data(), &H, head);
+  for (size_t k = 0; k < passes.size(); k++) memcpy(c->img.data() + head + k * 512, passes[k].data(), 512);
+  {
+    std::lock_guard<std::mutex> lk(cxp->mu);
+    if (hipSetDevice(cxp->device) != hipSuccess || !codec_on(*cxp, c)) {
+      delete c;
+      *err = "hipMalloc/hipMemcpy of the codec tables failed";
+      fail(LDH_E_NOMEM, "%s", *err);
+      return nullptr;
+    }
   }
   return c;
 }
 
 void ldh_codec_free(ldh_codec *c) {
   if (!c) return;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (c->d_tab) hipFree(c->d_tab);
+  for (auto &e : c->dev) {
+    hipSetDevice(e.first);
+    hipDeviceSynchronize();
+    hipFree(e.second);
+  }
   delete c;
 }
 
 namespace {
-int codec_decode_dev_locked(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+int codec_decode_dev_locked(Ctx &cx, const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
                             uint8_t *d_out, size_t out_stride, uint32_t *d_out_len, uint8_t *d_ok) {
   // one launch per gsub pass, ping-pong between the caller's slots and a scratch copy of them so
   // that the last pass lands in the caller's
-  if (int rc = ensure(g_codec_tmp, count * out_stride + 64)) return rc;
-  if (int rc = ensure(g_misc32a, count * 4 + 64)) return rc;
-  uint8_t *tmp = (uint8_t *)g_codec_tmp.p;
-  uint32_t *tmp_len = (uint32_t *)g_misc32a.p;
+  if (int rc = ensure(cx.codec_tmp, count * out_stride + 64)) return rc;
+  if (int rc = ensure(cx.misc32a, count * 4 + 64)) return rc;
+  const CodecTables *d_tab = codec_on(cx, c);
+  if (!d_tab) return fail(LDH_E_NOMEM, "codec upload to device %d failed", cx.device);
+  uint8_t *tmp = (uint8_t *)cx.codec_tmp.p;
+  uint32_t *tmp_len = (uint32_t *)cx.misc32a.p;
   const uint8_t *prev = nullptr;
   const uint32_t *prev_len = nullptr;
   for (uint32_t p = 0; p < c->npass; p++) {
@@ -1103,7 +1346,7 @@ int codec_decode_dev_locked(const ldh_codec *c, const uint8_t *d_in, const uint6
     uint8_t *dst = to_out ? d_out : tmp;
     uint32_t *dst_len = to_out ? d_out_len : tmp_len;
     LAUNCH("k_codec_decode_pass", k_codec_decode_pass, (uint32_t)count, kCodecThreads, 0, d_in, d_in_off, prev,
-           prev_len, (uint64_t)out_stride, (const CodecTables *)c->d_tab, p, dst, dst_len, d_ok);
+           prev_len, (uint64_t)out_stride, d_tab, p, dst, dst_len, d_ok);
     prev = dst;
     prev_len = dst_len;
   }
@@ -1114,73 +1357,73 @@ int codec_decode_dev_locked(const ldh_codec *c, const uint8_t *d_in, const uint6
 
 int ldh_codec_encode_batch_dev(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
                                uint8_t *d_out, size_t out_stride, uint32_t *d_out_len) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!c) return fail(LDH_E_ARG, "codec is null");
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
+  const CodecTables *d_tab = codec_on(cx, c);
+  if (!d_tab) return fail(LDH_E_NOMEM, "codec upload to device %d failed", cx.device);
   LAUNCH("k_codec_encode", k_codec_encode, (uint32_t)count, kCodecThreads, 0, d_in, d_in_off,
-         (const CodecTables *)c->d_tab, d_out, (uint64_t)out_stride, d_out_len);
+         d_tab, d_out, (uint64_t)out_stride, d_out_len);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int ldh_codec_decode_batch_dev(const ldh_codec *c, const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
                                uint8_t *d_out, size_t out_stride, uint32_t *d_out_len, uint8_t *d_ok) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!c) return fail(LDH_E_ARG, "codec is null");
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
-  return codec_decode_dev_locked(c, d_in, d_in_off, count, d_out, out_stride, d_out_len, d_ok);
+  return codec_decode_dev_locked(cx, c, d_in, d_in_off, count, d_out, out_stride, d_out_len, d_ok);
 }
 
 int ldh_codec_encode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off, size_t count,
                            uint8_t *out_base, size_t out_stride, uint32_t *out_len) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!c) return fail(LDH_E_ARG, "codec is null");
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   for (size_t s = 0; s < count; s++)
     if ((in_off[s + 1] - in_off[s]) * 2 > out_stride)
       return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
-  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
-  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
-  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
-  LAUNCH("k_codec_encode", k_codec_encode, (uint32_t)count, kCodecThreads, 0, (const uint8_t *)g_h_in.p,
-         (const uint64_t *)g_h_off.p, (const CodecTables *)c->d_tab, (uint8_t *)g_h_out.p, (uint64_t)out_stride,
-         (uint32_t *)g_h_len.p);
-  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
-                          g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  if (int rc = upload_inputs(cx, in_base, in_off, count)) return rc;
+  if (int rc = ensure(cx.h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(cx.h_len, count * 4 + 64)) return rc;
+  const CodecTables *d_tab = codec_on(cx, c);
+  if (!d_tab) return fail(LDH_E_NOMEM, "codec upload to device %d failed", cx.device);
+  LAUNCH("k_codec_encode", k_codec_encode, (uint32_t)count, kCodecThreads, 0, (const uint8_t *)cx.h_in.p,
+         (const uint64_t *)cx.h_off.p, d_tab, (uint8_t *)cx.h_out.p, (uint64_t)out_stride,
+         (uint32_t *)cx.h_len.p);
+  HIPCHK(hipMemcpyAsync(out_len, cx.h_len.p, count * 4, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, cx.h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          cx.stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));
   return 0;
 }
 
 int ldh_codec_decode_batch(const ldh_codec *c, const uint8_t *in_base, const uint64_t *in_off, size_t count,
                            uint8_t *out_base, size_t out_stride, uint32_t *out_len, uint8_t *ok) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
+  CTX_ENTER(cx);
   if (!c) return fail(LDH_E_ARG, "codec is null");
   if (!count) return 0;
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   for (size_t s = 0; s < count; s++)
     if (in_off[s + 1] - in_off[s] > out_stride)
       return fail(LDH_E_CAPACITY, "out_stride too small for stream %zu", s);
-  if (int rc = upload_inputs(in_base, in_off, count)) return rc;
-  if (int rc = ensure(g_h_out, count * out_stride + 64)) return rc;
-  if (int rc = ensure(g_h_len, count * 4 + 64)) return rc;
-  if (int rc = ensure(g_h_aux8, count + 64)) return rc;
-  if (int rc = codec_decode_dev_locked(c, (const uint8_t *)g_h_in.p, (const uint64_t *)g_h_off.p, count,
-                                       (uint8_t *)g_h_out.p, out_stride, (uint32_t *)g_h_len.p,
-                                       (uint8_t *)g_h_aux8.p))
+  if (int rc = upload_inputs(cx, in_base, in_off, count)) return rc;
+  if (int rc = ensure(cx.h_out, count * out_stride + 64)) return rc;
+  if (int rc = ensure(cx.h_len, count * 4 + 64)) return rc;
+  if (int rc = ensure(cx.h_aux8, count + 64)) return rc;
+  if (int rc = codec_decode_dev_locked(cx, c, (const uint8_t *)cx.h_in.p, (const uint64_t *)cx.h_off.p, count,
+                                       (uint8_t *)cx.h_out.p, out_stride, (uint32_t *)cx.h_len.p,
+                                       (uint8_t *)cx.h_aux8.p))
     return rc;
-  HIPCHK(hipMemcpyAsync(out_len, g_h_len.p, count * 4, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(ok, g_h_aux8.p, count, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, g_h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
-                          g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpyAsync(out_len, cx.h_len.p, count * 4, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipMemcpyAsync(ok, cx.h_aux8.p, count, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(hipMemcpy2DAsync(out_base, out_stride, cx.h_out.p, out_stride, out_stride, count, hipMemcpyDeviceToHost,
+                          cx.stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));
   return 0;
 }
 
@@ -1216,57 +1459,54 @@ int ldh_print6_decode(const uint8_t *in, size_t n, uint8_t *out, size_t cap, siz
 
 // ---- measurement -----------------------------------------------------------------
 int ldh_profile_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  prof_drain();
-  g_prof = on != 0;
+  CTX_ENTER(cx);
+  prof_drain(cx);
+  cx.prof = on != 0;
   return 0;
 }
 int ldh_profile_reset(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  prof_drain();
-  g_prof_entries.clear();
+  CTX_ENTER(cx);
+  prof_drain(cx);
+  cx.prof_entries.clear();
   return 0;
 }
 int ldh_profile_count(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  prof_drain();
-  return (int)g_prof_entries.size();
+  CTX_ENTER(cx);
+  prof_drain(cx);
+  return (int)cx.prof_entries.size();
 }
 int ldh_profile_get(int index, char *name, size_t name_cap, double *ms, uint64_t *launches) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  prof_drain();
-  if (index < 0 || index >= (int)g_prof_entries.size()) return fail(LDH_E_ARG, "bad profile index");
+  CTX_ENTER(cx);
+  prof_drain(cx);
+  if (index < 0 || index >= (int)cx.prof_entries.size()) return fail(LDH_E_ARG, "bad profile index");
   if (name && name_cap) {
-    strncpy(name, g_prof_entries[index].name.c_str(), name_cap - 1);
+    strncpy(name, cx.prof_entries[index].name.c_str(), name_cap - 1);
     name[name_cap - 1] = 0;
   }
-  if (ms) *ms = g_prof_entries[index].ms;
-  if (launches) *launches = g_prof_entries[index].launches;
+  if (ms) *ms = cx.prof_entries[index].ms;
+  if (launches) *launches = cx.prof_entries[index].launches;
   return 0;
 }
 int ldh_timer_start(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
-  HIPCHK(hipEventRecord(g_t0, g_stream));
+  CTX_ENTER(cx);
+  HIPCHK(hipEventRecord(cx.t0, cx.stream));
   return 0;
 }
 int ldh_timer_stop(double *ms) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
-  HIPCHK(hipEventRecord(g_t1, g_stream));
-  HIPCHK(hipEventSynchronize(g_t1));
+  CTX_ENTER(cx);
+  HIPCHK(hipEventRecord(cx.t1, cx.stream));
+  HIPCHK(hipEventSynchronize(cx.t1));
   float f = 0;
-  HIPCHK(hipEventElapsedTime(&f, g_t0, g_t1));
+  HIPCHK(hipEventElapsedTime(&f, cx.t0, cx.t1));
   if (ms) *ms = f;
   return 0;
 }
 
 // ---- inspection ---------------------------------------------------------------------
 int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (int rc = check_init()) return rc;
-  if (!g_have_last || stream >= g_last.count) return fail(LDH_E_ARG, "no such stream in the last batch");
-  const Batch &B = g_last;
+  CTX_ENTER(cx);
+  if (!cx.have_last || stream >= cx.last.count) return fail(LDH_E_ARG, "no such stream in the last batch");
+  const Batch &B = cx.last;
   const void *src = nullptr;
   size_t bytes = 0;
   switch (what) {
@@ -1278,7 +1518,7 @@ int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t
     default: return fail(LDH_E_ARG, "bad what");
   }
   if (bytes > cap_bytes) bytes = cap_bytes;
-  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipStreamSynchronize(cx.stream));
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   if (got_bytes) *got_bytes = bytes;
   return 0;

@@ -151,11 +151,14 @@ struct Batch {
   uint64_t out_stride;
   uint32_t *out_len;
   uint8_t *pad_bits;
+  uint32_t *too_long;   // device counter: streams longer than max_len (reported by ldh_sync)
 };
 
 __device__ inline uint32_t stream_len(const Batch &B, uint32_t s) {
   uint64_t n = B.in_off[s + 1] - B.in_off[s];
-  return n > B.max_len ? B.max_len : (uint32_t)n;  // longer streams are rejected on the host side
+  // (a stream longer than the caller's bound is rejected: k_plan counts it in *too_long, leaves out_len 0,
+  // and ldh_sync() fails with LDH_E_TOO_LONG; the clamp only keeps the other kernels inside their buffers)
+  return n > B.max_len ? B.max_len : (uint32_t)n;
 }
 
 }  // namespace ldh

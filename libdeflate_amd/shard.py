@@ -6,6 +6,9 @@ verification flag).  bench.py uses this with the "nccl" (= RCCL) backend and CUD
 tests run the same code with "gloo" and world_size 2.
 """
 import os
+import socket
+import subprocess
+import sys
 import time
 
 
@@ -76,3 +79,28 @@ def total(value, dist=None, torch=None, device="cpu"):
     if dist is None:
         return value
     return _reduce(dist, torch, value, torch.float64, dist.ReduceOp.SUM, device)
+
+
+def launch_ranks(argv, world, env=None):
+    """Start `world` fresh processes of `argv` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would) and wait for them.  Returns the first non-zero exit code, else 0.
+    The caller must not have touched the GPU: the children are new processes (no re-exec of this one), and
+    a parent that holds no GPU state just waits."""
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(world):
+        e = dict(os.environ if env is None else env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                  "MASTER_PORT": str(port)})
+        procs.append(subprocess.Popen(list(argv), env=e))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        for p in procs:  # (all have exited; nothing to kill -- report which rank failed first)
+            if p.returncode:
+                sys.stderr.write("rank process %d exited with %d\n" % (procs.index(p), p.returncode))
+    return rc

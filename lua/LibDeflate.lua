@@ -4,8 +4,10 @@ Drop-in for require("LibDeflate") on the hot path only: CompressDeflate / Compre
 Compress*WithDict / DecompressDeflate / DecompressZlib / Decompress*WithDict / Adler32 /
 CreateDictionary / EncodeForPrint / DecodeForPrint / CreateCodec / the WoW channel codecs.  Argument validation and the usage-error
 strings are kept in Lua exactly as the reference words them; everything after validation goes
-through the C ABI of include/libdeflate_hip.h.  The batched entry point is returned as a SECOND
-value of require (the reference's TestExported demands exactly its 22 keys on the first table).
+through the C ABI of include/libdeflate_hip.h.  The batched entry point is a module of its own,
+require("LibDeflateBatch") (lua/LibDeflateBatch.lua): the reference's TestExported demands exactly its
+22 keys on this table, and `require` hands back one value only, so it can be neither a 23rd key nor a
+second return value.
 
 NOT TESTED in the build image: no Lua/LuaJIT interpreter exists there (SURVEY.md 8.c).
 ]]
@@ -159,7 +161,9 @@ local function decompress(str, fmt, dictionary)
     local out = ffi.new("uint8_t[?]", cap)
     local ol, bl, st = ffi.new("size_t[1]"), ffi.new("size_t[1]"), ffi.new("int[1]")
     check(C.ldh_decompress(str, #str, fmt, h, out, cap, ol, bl, st))
-    if st[0] == 1 then cap = cap * 4  -- LDH_STATUS_OUTPUT_FULL: Lua strings simply grow
+    if st[0] == 1 then  -- LDH_STATUS_OUTPUT_FULL: Lua strings simply grow -- up to the library's limit
+      if cap >= 0xFFF00000 then error("libdeflate_hip: output of 4 GiB or more is not supported", 3) end
+      cap = math.min(cap * 4, 0xFFF00000)
     elseif st[0] ~= 0 then return nil, st[0]
     else return ffi.string(out, ol[0]), tonumber(bl[0]) end
   end
@@ -265,23 +269,36 @@ for name, spec in pairs({EncodeForWoWAddonChannel = {addon_codec, "Encode"}, Dec
   end
 end
 
--- Batched entry point (second return value of require): list of strings in, list of results out.
-local Batch = {}
-function Batch.Compress(strings, fmt, configs, dictionary)
-  local n = #strings
-  local level, strategy = -1, 0
-  if configs then level = configs.level or -1; strategy = STRATEGY[configs.strategy] or 0 end
-  local off = ffi.new("uint64_t[?]", n + 1)
-  local maxlen = 0
-  for i = 1, n do off[i] = off[i - 1] + #strings[i]; maxlen = math.max(maxlen, #strings[i]) end
-  local data = table.concat(strings)
-  local stride = tonumber(C.ldh_compress_bound(maxlen))
-  local out = ffi.new("uint8_t[?]", n * stride)
-  local ol, pb = ffi.new("uint32_t[?]", n), ffi.new("uint8_t[?]", n)
-  check(C.ldh_compress_batch(data, off, n, fmt or 0, level, strategy, handle_of(dictionary), out, stride, ol, pb))
-  local res, pads = {}, {}
-  for i = 1, n do res[i] = ffi.string(out + (i - 1) * stride, ol[i - 1]); pads[i] = pb[i - 1] end
-  return res, pads
+-- For test (reference :3419-3433): the same six names.
+local function LoadStringToTable(str, t, start, stop, offset)  -- :1184-1197: str[i] -> t[i - offset], start <= i <= stop
+  for i = start, stop do t[i - offset] = str:byte(i) end
+  return t
 end
-LibDeflate.internals = {IsValidDictionary = IsValidDictionary}
-return LibDeflate, Batch
+local function IsEqualAdler32(actual, expected)  -- :447-449
+  return (actual % 4294967296) == (expected % 4294967296)
+end
+local _byte_to_6bit_char, _6bit_to_byte = {}, {}  -- :3165-3297: a-z A-Z 0-9 ( )
+do
+  local alphabet = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789()"
+  for i = 0, 63 do
+    _byte_to_6bit_char[i] = alphabet:sub(i + 1, i + 1)
+    _6bit_to_byte[alphabet:byte(i + 1)] = i
+  end
+end
+local function InternalClearCache()
+  _chat_codec = nil
+  _addon_codec = nil
+end
+LibDeflate.internals = {
+  LoadStringToTable = LoadStringToTable,
+  IsValidDictionary = IsValidDictionary,
+  IsEqualAdler32 = IsEqualAdler32,
+  _byte_to_6bit_char = _byte_to_6bit_char,
+  _6bit_to_byte = _6bit_to_byte,
+  InternalClearCache = InternalClearCache,
+}
+
+-- What lua/LibDeflateBatch.lua builds on (not a key of the method table: kept in the loader's registry)
+package.loaded["LibDeflate.__hip"] = {C = C, ffi = ffi, check = check, handle_of = handle_of, STRATEGY = STRATEGY,
+                                      IsValidArguments = IsValidArguments}
+return LibDeflate

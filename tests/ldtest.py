@@ -169,3 +169,77 @@ def splitmix64(seed, n):
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
+
+
+# ---------------------------------------------------------------- crafted streams
+
+class BitWriter(object):
+    """LSB-first bit packer (RFC 1951 order) for hand-built test streams."""
+
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def bits(self, value, nbits):
+        self.acc |= (value & ((1 << nbits) - 1)) << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+            self.acc, self.n = 0, 0
+        return bytes(self.out)
+
+
+def truncated_dynamic_header_stream():
+    """A dynamic block whose header is cut off inside its code lengths (k_inflate): code-length code =
+    {0: 1 bit '0', 8: 1 bit '1'}; literal/length lengths 8 x255, 0, 8 (symbols 0..254 and 256: a complete code); then
+    the stream ends.  The 29 remaining length codes and the 30 distance lengths decode from the zero bits past the end
+    (neither the reference nor puff's order of checks looks at the bits left inside the header, LD:2506-2615), so the
+    block body starts some 60 bits beyond the input: the reference decodes literal 0 from eight zero bits and then
+    reports 2 (LD:2428)."""
+    w = BitWriter()
+    w.bits(1, 1)    # BFINAL
+    w.bits(2, 2)    # dynamic
+    w.bits(29, 5)   # HLIT: 286 literal/length codes
+    w.bits(29, 5)   # HDIST: 30 distance codes
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    w.bits(1, 4)    # HCLEN: 5 code-length code lengths (16, 17, 18, 0, 8)
+    for sym in order[:5]:
+        w.bits(1 if sym in (0, 8) else 0, 3)
+    for _ in range(255):
+        w.bits(1, 1)   # length 8
+    w.bits(0, 1)       # symbol 255: length 0
+    w.bits(1, 1)       # symbol 256: length 8
+    return w.done()
+
+
+def unique_chars_string(rng, n):
+    """GetRandomStringUniqueChars of tests/Test.lua:225-247: n <= 256 distinct bytes in random order; beyond 256, random
+    bytes inserted at random places of a permutation of all 256."""
+    perm = [int(x) for x in rng.permutation(256)]
+    if n <= 256:
+        return bytes(perm[:n])
+    for _ in range(n - 256):
+        perm.insert(int(rng.integers(0, len(perm) + 1)), int(rng.integers(0, 256)))
+    return bytes(perm)
+
+
+def dict_bound_cases(trials=10):
+    """(dictionary, string, bound on the raw-deflate size at level 7) of tests/Test.lua:1893-1957."""
+    rng = np.random.default_rng(1893)
+    out = []
+    for _ in range(trials):
+        s = unique_chars_string(rng, 3)
+        out.append((s, s, 4))                          # TestLength3String1
+        s = unique_chars_string(rng, 3)
+        out.append((s[:2], s[2:3] + s, 5))             # TestLength3String2: the last two dictionary bytes are hashed
+        s = unique_chars_string(rng, 3)
+        out.append((s[:1], s[1:3] + s, 6))             # TestLength3String3
+        for n, bound in ((257, 5), (258, 4), (259, 5)):
+            s = unique_chars_string(rng, n)
+            out.append((s, s, bound))
+    return out

@@ -20,29 +20,76 @@ def test_library_exports_every_declared_symbol():
     assert N.lib.ldh_compress_bound(0) % 16 == 0 and N.lib.ldh_compress_bound(131072) >= 131072 + 20
 
 
+def _raises(fn, msg):
+    from libdeflate_amd.LibDeflate import UsageError
+    with pytest.raises(UsageError) as e:
+        fn()
+    assert str(e.value) == msg, (str(e.value), msg)
+
+
 def test_usage_errors_match_reference_strings():
-    from libdeflate_amd.LibDeflate import LibDeflate as LD, UsageError
-    cases = [
-        (lambda: LD.CompressDeflate(None), "Usage: LibDeflate:CompressDeflate(str, configs): 'str' - string expected got 'nil'."),
-        (lambda: LD.CompressDeflate(b"", 1), "Usage: LibDeflate:CompressDeflate(str, configs): 'configs' - nil or table expected got 'number'."),
-        (lambda: LD.CompressDeflate(b"", {"level": 10}), "Usage: LibDeflate:CompressDeflate(str, configs): 'configs' - unsupported 'level': 10."),
-        (lambda: LD.CompressZlib(b"", {"strategy": "x"}), "Usage: LibDeflate:CompressZlib(str, configs): 'configs' - unsupported 'strategy': 'x'."),
-        (lambda: LD.CompressZlib(b"", {"foo": 1}), "Usage: LibDeflate:CompressZlib(str, configs): 'configs' - unsupported table key in the configs: 'foo'."),
-        (lambda: LD.CompressDeflateWithDict(b"", None), "Usage: LibDeflate:CompressDeflateWithDict(str, dictionary, configs): 'dictionary' - table expected got 'nil'."),
-        (lambda: LD.DecompressDeflate(1), "Usage: LibDeflate:DecompressDeflate(str): 'str' - string expected got 'number'."),
-        (lambda: LD.DecompressZlibWithDict(b"", {}), "Usage: LibDeflate:DecompressZlibWithDict(str, dictionary): 'dictionary' - table expected got 'table'."),
-        (lambda: LD.Adler32(None), "Usage: LibDeflate:Adler32(str): 'str' - string expected got 'nil'."),
-        (lambda: LD.EncodeForPrint(None), "Usage: LibDeflate:EncodeForPrint(str): 'str' - string expected got 'nil'."),
-        (lambda: LD.DecodeForPrint(3), "Usage: LibDeflate:DecodeForPrint(str): 'str' - string expected got 'number'."),
-        (lambda: LD.CreateDictionary(b"", 0, 1), "Usage: LibDeflate:CreateDictionary(str, strlen, adler32): 'str' - Empty string is not allowed."),
-        (lambda: LD.CreateDictionary(b"a", 2, 1), None),
-        (lambda: LD.CreateDictionary(b"a" * 32769, 32769, 1), "Usage: LibDeflate:CreateDictionary(str, strlen, adler32): 'str' - string longer than 32768 bytes is not allowed. Got 32769 bytes."),
-    ]
-    for fn, msg in cases:
-        with pytest.raises(UsageError) as e:
-            fn()
-        if msg is not None:
-            assert str(e.value) == msg
+    """Every `Usage:` assertion of tests/Test.lua:2290-2503, replayed through the Python mirror (validation runs before
+    any device work, so no GPU is needed)."""
+    from libdeflate_amd.LibDeflate import Dictionary, LibDeflate as LD
+    import copy
+    good = Dictionary(b"abcdefgh", 0x0E000325)
+
+    # T:2290-2340 TestInvalidCompressDecompressArgs, for the eight methods of T:2404-2456
+    methods = [
+        ("CompressDeflate", "str, configs", False, True), ("CompressDeflateWithDict", "str, dictionary, configs", True, True),
+        ("CompressZlib", "str, configs", False, True), ("CompressZlibWithDict", "str, dictionary, configs", True, True),
+        ("DecompressDeflate", "str", False, False), ("DecompressZlib", "str", False, False),
+        ("DecompressDeflateWithDict", "str, dictionary", True, False), ("DecompressZlibWithDict", "str, dictionary", True, False)]
+    for name, sig, with_dict, with_cfg in methods:
+        pre = "Usage: LibDeflate:%s(%s): " % (name, sig)
+        f = getattr(LD, name)
+
+        def call(s, d, c):
+            args = [s] + ([d] if with_dict else []) + ([c] if with_cfg else [])
+            return f(*args)
+        _raises(lambda: call(None, good, None), pre + "'str' - string expected got 'nil'.")      # T:2292
+        _raises(lambda: call({}, good, None), pre + "'str' - string expected got 'table'.")     # T:2294
+        if with_dict:                                                                         # T:2249-2287
+            _raises(lambda: call(b"", None, {}), pre + "'dictionary' - table expected got 'nil'.")
+            for field, value in (("string_table", 1), ("string_table", None), ("strlen", {}), ("strlen", 32769),
+                                 ("string_table", b"abcdefgha"), ("hash_tables", 1), ("hash_tables", None), ("adler32", None)):
+                bad = copy.copy(good)
+                setattr(bad, field, value)
+                _raises(lambda: call(b"", bad, {}), pre + "'dictionary' - corrupted dictionary.")
+        if with_cfg:                                                                          # T:2307-2336
+            _raises(lambda: call(b"", good, 1), pre + "'configs' - nil or table expected got 'number'.")
+            _raises(lambda: call(b"", good, {"not_a_key": 1}),
+                    pre + "'configs' - unsupported table key in the configs: 'not_a_key'.")
+            _raises(lambda: call(b"", good, {"level": 10}), pre + "'configs' - unsupported 'level': 10.")
+            _raises(lambda: call(b"", good, {"strategy": "dne"}), pre + "'configs' - unsupported 'strategy': 'dne'.")
+
+    # T:2342-2350
+    _raises(lambda: LD.Adler32(None), "Usage: LibDeflate:Adler32(str): 'str' - string expected got 'nil'.")
+    _raises(lambda: LD.Adler32({}), "Usage: LibDeflate:Adler32(str): 'str' - string expected got 'table'.")
+    # T:2351-2368 (the checks that need Adler32(str) run on the GPU: tests/test_gpu_round2.py)
+    pre = "Usage: LibDeflate:CreateDictionary(str, strlen, adler32): "
+    _raises(lambda: LD.CreateDictionary(None, 1, 0x00320032), pre + "'str' - string expected got 'nil'.")
+    _raises(lambda: LD.CreateDictionary({}, 1, 0x00320032), pre + "'str' - string expected got 'table'.")
+    _raises(lambda: LD.CreateDictionary(b"1", None, 0x00320032), pre + "'strlen' - number expected got 'nil'.")
+    _raises(lambda: LD.CreateDictionary(b"1", 1, None), pre + "'adler32' - number expected got 'nil'.")
+    _raises(lambda: LD.CreateDictionary(b"", 0, 1), pre + "'str' - Empty string is not allowed.")               # T:2370
+    _raises(lambda: LD.CreateDictionary(b"\0" * 32769, 32769, 1),
+            pre + "'str' - string longer than 32768 bytes is not allowed. Got 32769 bytes.")                    # T:2374
+    _raises(lambda: LD.CreateDictionary(b"\0" * 32768, 32767, 1),
+            pre + "'strlen' does not match the actual length of 'str'. 'strlen': 32767, '#str': 32768 ."
+                  " Please check if 'str' is modified unintentionally.")                                       # T:2384
+    # T:2457-2469
+    pre = "Usage: LibDeflate:CreateCodec(reserved_chars, escape_chars, map_chars): All arguments must be string."
+    _raises(lambda: LD.CreateCodec(None, b"", b""), pre)
+    _raises(lambda: LD.CreateCodec(b"", None, b""), pre)
+    _raises(lambda: LD.CreateCodec(b"", b"", None), pre)
+    # T:2481-2502 (codec:Encode / codec:Decode need a codec handle: GPU tests)
+    for name in ("EncodeForWoWAddonChannel", "DecodeForWoWAddonChannel", "EncodeForWoWChatChannel",
+                 "DecodeForWoWChatChannel", "EncodeForPrint", "DecodeForPrint"):
+        fn = getattr(LD, name)
+        if "WoW" in name:
+            continue  # (these build their codec first: replayed on the GPU)
+        _raises(lambda: fn(None), "Usage: LibDeflate:%s(str): 'str' - string expected got 'nil'." % name)
 
 
 def test_product_has_no_cpu_fallback():

@@ -74,13 +74,18 @@ def test_roundtrip_dictionary(dlen):
 
 
 def test_dictionary_size_pins():
-    # tests/Test.lua:1893-1957: dict == str of unique bytes, level 7
-    for n, bound in ((3, 4), (257, 5), (258, 4), (259, 5)):
-        d = bytes((i * 7 + 3) & 255 for i in range(n)) if n <= 256 else bytes(range(256)) + bytes(range(n - 256))
-        if n > 256:
-            continue  # unique-char strings longer than 256 do not exist; the reference repeats chars
-        c, _ = o_compress(d, level=7, dict=d)
-        assert len(c) <= bound
+    # tests/Test.lua:1893-1957 (TestLength3String1/2/3, TestLength257/258/259String), all ten trials each, with
+    # CheckDictEffectiveness (T:762-807): level 7, round trips, the dictionary must pay off
+    from ldtest import dict_bound_cases
+    for dct, s, bound in dict_bound_cases():
+        c, _ = o_compress(s, level=7, dict=dct)
+        assert len(c) <= bound, (len(dct), len(c), bound)
+        assert o_decompress(c, dict=dct) == (s, 0)
+        plain, _ = o_compress(s, level=7)
+        assert len(plain) - len(c) > 0                                  # T:775-777
+        z, _ = o_compress(s, zlib=True, level=7, dict=dct)
+        assert o_decompress(z, zlib=True, dict=dct) == (s, 0)
+        assert len(o_compress(s, zlib=True, level=7)[0]) - len(z) > -4  # T:794-799
 
 
 def test_foreign_zlib_streams_inflate():
