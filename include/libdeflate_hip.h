@@ -128,6 +128,19 @@ int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size
                              int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
                              uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status);
 
+/* ldh_decompress_batch_dev for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results;
+ * it calls no hipMalloc / hipFree: the per-stream scratch of the zlib trailer check lives in static device
+ * memory (8 bytes x LDH_NOALLOC_MAX_STREAMS per GPU, held until the process ends).  count above
+ * LDH_NOALLOC_MAX_STREAMS gives LDH_E_CAPACITY; a dictionary must already be resident on the device
+ * (it is after ldh_dict_create on this context or any earlier call with it), else LDH_E_ARG.  Profiling is
+ * off for the call.  Calls on one GPU share the scratch: do not overlap them (the library's stream and
+ * context lock order calls made through one context). */
+#define LDH_NOALLOC_MAX_STREAMS 65536
+int ldh_decompress_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
+                                     int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
+                                     uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status);
+
 /* Same, for inputs laid out as ldh_compress_batch_dev leaves them: stream s is
  * d_in + s*in_stride, d_in_len[s] bytes (so a device-resident round trip needs no repacking). */
 int ldh_decompress_slots_dev(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_len,

@@ -74,6 +74,7 @@ _SIGS = {
                                          u32p, u8p]),
     "ldh_decompress_batch": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_void_p, u8p, sz, u32p, u32p, i32p]),
     "ldh_decompress_batch_dev": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_void_p, u8p, sz, u32p, u32p, i32p]),
+    "ldh_decompress_batch_dev_noalloc": (C.c_int, [u8p, u64p, sz, C.c_int, C.c_void_p, u8p, sz, u32p, u32p, i32p]),
     "ldh_decompress_slots_dev": (C.c_int, [u8p, sz, u32p, sz, C.c_int, C.c_void_p, u8p, sz, u32p, u32p, i32p]),
     "ldh_adler32_batch": (C.c_int, [u8p, u64p, sz, u32p]),
     "ldh_adler32_batch_dev": (C.c_int, [u8p, u64p, sz, u32p]),

@@ -22,6 +22,9 @@
 
 using namespace ldh;
 
+#ifndef LDH_NOALLOC_MAX_STREAMS
+#define LDH_NOALLOC_MAX_STREAMS 65536  // LDH_NOALLOC_MAX_STREAMS of the header: 2 x 4 bytes of static device memory each
+#endif
 
 struct ldh_dict {
   std::vector<uint8_t> bytes;  // host copy: every device a context runs on gets its own upload
@@ -36,6 +39,13 @@ struct ldh_codec {
   std::mutex mu;
   std::vector<std::pair<int, ldh::CodecTables *>> dev;
 };
+
+// ---- the no-allocation entry point's scratch (ldh_decompress_batch_dev_noalloc) --------------------
+// File-scope device memory, one copy per GPU, held until the process ends: the zlib trailer values k_inflate reads
+// and the Adler-32 sums k_adler32 computes for kNoAllocMaxStreams streams.  In host code this name is only a
+// stand-in; each context keeps the address hipGetSymbolAddress gave for its device (Ctx::noalloc).
+constexpr size_t kNoAllocMaxStreams = LDH_NOALLOC_MAX_STREAMS;
+static __device__ __align__(256) uint32_t scratch[2 * kNoAllocMaxStreams];
 
 namespace {
 
@@ -79,6 +89,7 @@ struct Ctx {
   DevBuf h_in, h_off, h_out, h_len, h_aux8, h_aux32a, h_aux32b, codec_tmp;
   Slot slot[3];
   uint32_t *flags = nullptr;    // [0] streams longer than max_in_len since the last ldh_sync (k_plan)
+  uint32_t *noalloc = nullptr;  // this device's copy of `scratch`
   bool attr_done = false;
   // last compress batch (for ldh_debug_fetch)
   Batch last{};
@@ -382,14 +393,19 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
 int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                           size_t in_stride, size_t count, int fmt,
                           const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
-                          uint32_t *d_bytes_left, int32_t *d_status) {
+                          uint32_t *d_bytes_left, int32_t *d_status, uint32_t *scratch2 = nullptr) {
   if (count == 0) return 0;
   if (fmt != 0 && fmt != 1) return fail(LDH_E_ARG, "bad fmt %d", fmt);
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
-  // zlib trailer values read by k_inflate / Adler-32 sums of the results
-  if (int rc = ensure(cx.misc32a, count * 4 + 64)) return rc;
-  if (int rc = ensure(cx.misc32b, count * 4 + 64)) return rc;
-  uint32_t *expect = (uint32_t *)cx.misc32a.p, *actual = (uint32_t *)cx.misc32b.p;
+  // zlib trailer values read by k_inflate / Adler-32 sums of the results: library workspace, or (the
+  // no-allocation entry point) the two halves of the caller-independent static scratch
+  uint32_t *expect = scratch2, *actual = scratch2 ? scratch2 + kNoAllocMaxStreams : nullptr;
+  if (!scratch2) {
+    if (int rc = ensure(cx.misc32a, count * 4 + 64)) return rc;
+    if (int rc = ensure(cx.misc32b, count * 4 + 64)) return rc;
+    expect = (uint32_t *)cx.misc32a.p;
+    actual = (uint32_t *)cx.misc32b.p;
+  }
   const uint8_t *d_dict = nullptr;
   if (dict && !(d_dict = dict_on(cx, dict))) return fail(LDH_E_NOMEM, "dictionary upload to device %d failed", cx.device);
   InflateArgs A{};
@@ -561,13 +577,17 @@ Ctx *ctx_create(int device) {  // g_mu held
   }
   Ctx *c = new Ctx;
   c->device = device;
+  void *sym = nullptr;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
-      (e = hipMalloc((void **)&c->flags, 256)) != hipSuccess || (e = hipMemset(c->flags, 0, 256)) != hipSuccess) {
+      (e = hipMalloc((void **)&c->flags, 256)) != hipSuccess || (e = hipMemset(c->flags, 0, 256)) != hipSuccess ||
+      // this GPU's copy of the no-allocation scratch: its address here, never the array's name, is what kernels get
+      (e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch))) != hipSuccess) {
     fail(LDH_E_HIP, "context on device %d: %s", device, hipGetErrorString(e));
     delete c;
     return nullptr;
   }
+  c->noalloc = (uint32_t *)sym;
   return c;
 }
 void ctx_destroy(Ctx *c) {
@@ -813,6 +833,34 @@ int ldh_decompress_slots_dev(const uint8_t *d_in, size_t in_stride, const uint32
   if (!d_in_len) return fail(LDH_E_ARG, "d_in_len is required");
   return decompress_dev_locked(cx, d_in, nullptr, d_in_len, in_stride, count, fmt, dict, d_out, out_stride, d_out_len,
                                d_bytes_left, d_status);
+}
+
+// The one entry point that allocates nothing (callers under HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): ldh_decompress_batch_dev with its two per-stream scratch arrays (zlib trailer values, Adler-32
+// sums) in this GPU's copy of the file-scope `scratch` instead of grow-only workspace.  Every stream's entries are
+// written before they are read (k_inflate and k_adler32 write all `count` of them, k_zlib_check reads them), so
+// nothing has to be cleared between calls; calls that overlap on one GPU would share the array and race (the
+// context mutex serialises the enqueue, the library stream the execution).
+int ldh_decompress_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, int fmt,
+                                     const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
+                                     uint32_t *d_bytes_left, int32_t *d_status) {
+  CTX_ENTER(cx);
+  if (count > kNoAllocMaxStreams)
+    return fail(LDH_E_CAPACITY, "ldh_decompress_batch_dev_noalloc takes at most %zu streams per call (got %zu)",
+                kNoAllocMaxStreams, count);
+  if (dict) {  // the dictionary must already be on this GPU (ldh_dict_create on this context, or an earlier call)
+    ldh_dict *d = const_cast<ldh_dict *>(dict);
+    std::lock_guard<std::mutex> dl(d->mu);
+    bool here = false;
+    for (auto &e : d->dev) here = here || e.first == cx.device;
+    if (!here) return fail(LDH_E_ARG, "dictionary is not resident on device %d (uploading it would allocate)", cx.device);
+  }
+  const bool prof = cx.prof;  // (profiling brackets launches with events from a pool that may have to grow)
+  cx.prof = false;
+  const int rc = decompress_dev_locked(cx, d_in, d_in_off, nullptr, 0, count, fmt, dict, d_out, out_stride, d_out_len,
+                                       d_bytes_left, d_status, cx.noalloc);
+  cx.prof = prof;
+  return rc;
 }
 
 int ldh_adler32_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, uint32_t *d_adler) {
