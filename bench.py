@@ -74,7 +74,11 @@ def cpu_baseline(host_rows, level, seconds_target=12.0):
     over a bounded sample of the batch.  Returns dict for the JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ldtest as T
-    cores = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+    # every host core this process may use: the affinity mask, capped by the share the box grants one GPU
+    # (OMP_NUM_THREADS = 16 there, while os.cpu_count() shows the whole 8-GPU machine)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(visible, share) if share > 0 else visible)
     rows = [r.tobytes() for r in host_rows]
 
     def work(s):
@@ -93,9 +97,11 @@ def cpu_baseline(host_rows, level, seconds_target=12.0):
     with ThreadPoolExecutor(max_workers=cores) as ex:  # ctypes releases the GIL inside the oracle
         nbytes = sum(ex.map(work, sample))
     dt = time.time() - t0
-    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "host_cpus_visible": visible, "kind": "port",
             "sample": "%d of the batch's 128 KiB streams, compress(level %d)+decompress by oracle/ld_oracle.c, "
-                      "%d threads, %.1f s" % (nsample, level, cores, dt)}
+                      "%d threads (all cores granted to this GPU: OMP_NUM_THREADS=%s of %d visible), %.1f s; the reference itself "
+                      "(Lua) cannot run here: LuaJIT baseline unavailable, its published figure is 4.1 MB/s per core"
+                      % (nsample, level, cores, os.environ.get("OMP_NUM_THREADS", "unset"), visible, dt)}
 
 
 def main():
@@ -108,6 +114,8 @@ def main():
     ap.add_argument("--level", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-levels", action="store_true", help="skip the one-step runs at levels 1 and 8")
+    ap.add_argument("--no-extra-rows", action="store_true",
+                    help="skip the secondary entries (configs[1], configs[3], C5, host API) measured after the headline")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher check (CPU, gloo): start the ranks, run the barrier / MAX-over-ranks protocol around "
                          "empty steps and print the line with value null; no GPU work")
@@ -214,6 +222,18 @@ def main():
             ok = ok and cbuf[i * stride: i * stride + int(lens[i])].tobytes() == want
     ok = shard.all_true(ok, dist, torch, dev)
 
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra_rows and L == STREAM_LEN:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_rows as R
+        del comp, back  # (the rows allocate their own buffers)
+        extra["configs1_small_strings"] = R.row_small_strings(torch, dev, SEED, T=T)
+        extra["configs3_zlib_dictionary"] = R.row_zlib_dictionary(
+            torch, dev, data, min(S, 2048), L, os.path.join(ROOT, "tests", "golden", "dictionary32768.txt"), level=args.level, T=T)
+        extra["configs4_mixed_inflate_print"] = R.row_mixed_inflate_print(torch, dev, data, S, L)
+        extra["host_api_pcie_inclusive"] = R.row_host_api(torch, data, min(S, 2048), L, level=args.level)
+        ok = ok and all(v.get("verified", True) if "levels" not in v else all(x["verified"] for x in v["levels"].values())
+                        for v in extra.values())
     if rank == 0:
         in_bytes = S * L * args.steps * world
         value = in_bytes / dt / 1e9
@@ -253,6 +273,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3},
         }
+        if extra:
+            line["other_configs"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_rows, args.level)
         print(json.dumps(line), flush=True)

@@ -341,7 +341,7 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // 32-bit offset `rel` into the staged window plus a 64-bit base that changes only when the
 // window is reloaded.
 __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
-                            uint32_t *s_in /* LDS, 64 dwords */) {
+                            uint32_t *s_in /* LDS, 64 + 4 dwords */, uint32_t *s_tk /* LDS, 64 dwords */) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
     ext = O.dlen;
@@ -357,15 +357,12 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   uint32_t rel = 0;                // bit offset of the current position in the window
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
   bool have = false;
-  // match copies in flight: bytes loaded in one round are stored in the next (plen 0: free)
-#ifndef LDH_INFLATE_PEND
-#define LDH_INFLATE_PEND 0  // match copies deferred to the next round (so that their loads overlap its decode).  Slots cost their
-// checks in every round: 4 -> 1 was worth 0.8 ms per GiB, and with the uniform copy loops below none at all is fastest
-// (0 / 1 / 2: 13.0 / 13.3 / 13.6 ms); the mechanism stays for batches too small to hide the loads behind other waves.
+  const unsigned long long le_mask = (2ull << lane) - 1ull;  // lanes 0..lane
+#ifndef LDH_INFLATE_DEFER
+#define LDH_INFLATE_DEFER 0  // measured: 12.0 ms per GiB deferred against 11.2 stored at once (8192 streams)
 #endif
-  constexpr int kPend = LDH_INFLATE_PEND;
-  uint32_t pval[kPend + 1] = {}, plen[kPend + 1] = {}, pdst[kPend + 1] = {};  // (+1: kPend may be 0)
-  uint32_t pend_lo = 0xFFFFFFFFu;  // lowest output position with a store in flight
+  constexpr bool kDefer = LDH_INFLATE_DEFER != 0;
+  uint32_t pend_v = 0, pend_n = 0, pend_op = 0;  // a round's output bytes kept in registers for one round (kDefer)
   for (;;) {
     if (!have || rel >= 58 * 32) {
       if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
@@ -420,9 +417,12 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     // (slow / invalid / end of block) advances by 64 bits.
     const bool hard = slow | bad | is_eob;
     const uint32_t P = hard ? 64u : (tok_bits | (out_len << 8));
+    // S: bit j set = a token's output starts j bytes into the round's output (feeds the one-pass copy below)
     uint32_t acc = 0, k = 0, my_acc = 0xFFFFFFFFu;
+    unsigned long long S = 0;
     do {
       my_acc = lane == k ? acc : my_acc;
+      S |= 1ull << ((acc >> 8) & 63);
       acc += __builtin_amdgcn_readlane(P, k);
       k = acc & 0xff;
     } while (k < 64);
@@ -436,88 +436,67 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     const unsigned long long stops = ballot64(is_tok & (hard | err11 | full | exh));
     const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
     const bool commit = is_tok & (lane < first);
-    // ---- copies deferred by the previous round: their loads have had a whole round to land
+    // ---- this round's output.  The usual case -- at most 64 bytes, every match source older than the bytes still
+    // in flight and inside the output -- is written in ONE pass, one lane per output byte: the byte's token is found
+    // from S, literals come from that token's lane, match bytes are loaded from `dist` back, all matches of
+    // the round by the same load instruction (one memory latency per round instead of one per match, and no
+    // per-match loop).  With LDH_INFLATE_DEFER the bytes are stored a round later, so that the loads' latency
+    // overlaps the next round's decode instead of ending this one.
+    const uint32_t n_out = first == 64 ? acc >> 8 : __builtin_amdgcn_readlane(my_off, first);
+    const bool cm = commit & is_len;
+    // output below `fenced` is complete once the fence below has run (pend_n bytes from pend_op on are still in
+    // registers: loaded or decoded in the previous round, not stored yet)
+    const uint32_t fenced = pend_n ? pend_op : op;
+    // a match that reads bytes not yet stored (that includes every self-overlapping one) or the dictionary
+    const bool odd = cm & ((my_pos + mlen > fenced + dist) | (dist > my_pos));
+    const bool fast = n_out <= 64 && ballot64(odd) == 0;
+    // every store of earlier rounds must be visible to this round's match sources (this also waits for the loads
+    // of the deferred bytes)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // every store issued before this point is complete: all output below `fenced` is readable
-    const uint32_t fenced = pend_lo < op ? pend_lo : op;
-#pragma unroll
-    for (int q = 0; q < kPend; q++) {
-      if (lane < plen[q]) out[pdst[q] + lane] = (uint8_t)pval[q];
-      plen[q] = 0;
+    if (pend_n) {
+      if (lane < pend_n) out[pend_op + lane] = (uint8_t)pend_v;
+      pend_n = 0;
+      if (!fast) {  // the in-order path below may read them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
     }
-    pend_lo = 0xFFFFFFFFu;
-    // ---- literals of this round
-    if (commit & is_lit) out[my_pos] = (uint8_t)sym;
-    // ---- matches of this round
-    const bool cm = commit & is_len;
-    unsigned long long mm = ballot64(cm);
-    if (mm) {
-      // a match whose source [dst-dist, dst-dist+len) lies wholly below `fenced` depends on
-      // nothing in flight (this also excludes every self-overlapping match, dist < len)
-      const bool near = cm & (my_pos + mlen > fenced + dist);
-      if (ballot64(near) == 0) {
-        // the first kPend of them: load now (one lane per byte), store in the next round
-#pragma unroll
-        for (int q = 0; q < kPend; q++) {
-          if (mm) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
-            const uint32_t d = __builtin_amdgcn_readlane(dist, j);
-            const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
-            if (len <= kWave) {
-              if (d <= dst) {  // (uniform) the source lies in the output: no per-lane pointer select
-                if (lane < len) pval[q] = out[dst - d + lane];
-              } else if (lane < len) {
-                const uint32_t a = dst + lane;
-                pval[q] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
-              }
-              plen[q] = len;
-              pdst[q] = dst;
-              pend_lo = pend_lo < dst ? pend_lo : dst;
-            } else {
-              for (uint32_t i = lane; i < len; i += kWave) {
-                const uint32_t a = dst + i;
-                out[a] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
-              }
-            }
+    if (fast) {
+      // a token's lane leaves what its bytes are made of (the literal, or the distance) at the token's output offset;
+      // a byte's lane finds its token's offset as the highest bit of S at or below its own (LDS operations of one
+      // wave execute in order: no barrier between the write and the read)
+      if (is_tok & (my_off < 64)) s_tk[my_off] = is_len ? (0x80000000u | dist) : sym;
+      const unsigned long long below = S & le_mask;
+      const uint32_t info = s_tk[below ? 63 - __builtin_clzll(below) : 0];
+      uint32_t v = info;
+      if (lane < n_out && (info >> 31)) v = out[op + lane - (info & 0xFFFFu)];
+      if (kDefer) {
+        pend_v = v;
+        pend_n = n_out;
+        pend_op = op;
+      } else if (lane < n_out) {
+        out[op + lane] = (uint8_t)v;
+      }
+    } else {
+      if (commit & is_lit) out[my_pos] = (uint8_t)sym;
+      unsigned long long mm = ballot64(cm);
+      while (mm) {  // in order, each one seeing everything stored before it
+        const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+        mm &= mm - 1;
+        const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
+        const uint32_t d = __builtin_amdgcn_readlane(dist, j);
+        const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (d >= len && d <= dst) {  // (uniform) no overlap with itself, source in the output
+          for (uint32_t i = lane; i < len; i += kWave) out[dst + i] = out[dst - d + i];
+        } else {
+          for (uint32_t i = lane; i < len; i += kWave) {
+            const uint32_t a = dst + (d >= len ? i : (i % d));
+            out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
           }
         }
-        while (mm) {
-          const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-          mm &= mm - 1;
-          const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
-          const uint32_t d = __builtin_amdgcn_readlane(dist, j);
-          const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
-          if (d <= dst) {  // (uniform) the source lies in the output: no per-lane pointer select
-            for (uint32_t i = lane; i < len; i += kWave) out[dst + i] = out[dst - d + i];
-          } else {
-            for (uint32_t i = lane; i < len; i += kWave) {
-              const uint32_t a = dst + i;
-              out[a] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
-            }
-          }
-        }
-      } else {
-        // in order, each one seeing everything stored before it
-        do {
-          const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-          mm &= mm - 1;
-          const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
-          const uint32_t d = __builtin_amdgcn_readlane(dist, j);
-          const uint32_t dst = op + __builtin_amdgcn_readlane(my_off, j);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          if (d >= len && d <= dst) {  // (uniform) no overlap with itself, source in the output
-            for (uint32_t i = lane; i < len; i += kWave) out[dst + i] = out[dst - d + i];
-          } else {
-            for (uint32_t i = lane; i < len; i += kWave) {
-              const uint32_t a = dst + (d >= len ? i : (i % d));
-              out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
-            }
-          }
-        } while (mm);
       }
     }
     if (first == 64) {  // the whole window was consumed
@@ -525,14 +504,10 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       rel += k;
       continue;
     }
-    // ---- a stop: nothing may stay deferred past this round
-    if (pend_lo != 0xFFFFFFFFu) {
-#pragma unroll
-      for (int q = 0; q < kPend; q++) {
-        if (lane < plen[q]) out[pdst[q] + lane] = (uint8_t)pval[q];
-        plen[q] = 0;
-      }
-      pend_lo = 0xFFFFFFFFu;
+    // ---- a stop: nothing stays deferred past this round (the paths below read or extend the output)
+    if (pend_n) {
+      if (lane < pend_n) out[pend_op + lane] = (uint8_t)pend_v;
+      pend_n = 0;
     }
     // ---- the stopping token
     const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
@@ -571,6 +546,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   __shared__ DistTab DT;
   __shared__ uint8_t lens[320 + 32];
   __shared__ uint32_t s_in[kWave + 4];
+  __shared__ uint32_t s_tk[kWave];
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
   const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
@@ -632,7 +608,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           build_table(DT, lens + 288, 32, 5, DistTab::kBits, lane, kLutDist);
           fixed_ready = 1;
         }
-        status = decode_block(LT, DT, R, O, lane, s_in);
+        status = decode_block(LT, DT, R, O, lane, s_in, s_tk);
       } else if (type == 2) {  // LD:2506-2615
         fixed_ready = 0;
         const uint32_t nlen = br_read(R, 5, lane) + 257;
@@ -690,7 +666,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
         err = build_table(DT, lens + 320, (int)ndist, 15, DistTab::kBits, lane, kLutDist);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
-        status = decode_block(LT, DT, R, O, lane, s_in);
+        status = decode_block(LT, DT, R, O, lane, s_in, s_tk);
       } else {
         status = -1;
       }

@@ -385,6 +385,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
 #endif
 constexpr uint32_t kTile = LDH_MATCH_TILE;  // a multiple of 4096, at most 20480 (LDS; one deflate-block end per tile)
 constexpr int kMatchThreads = LDH_MATCH_THREADS;
+constexpr int kMatchThreadsNarrow = 256;
+constexpr uint32_t kMatchNarrowMaxV = 16384;  // dictionary + stream up to this long: the narrow version, LDS sized to the batch
 constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
 constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
 constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
@@ -404,11 +406,15 @@ constexpr uint32_t kMatchSteps = LDH_MATCH_STEPS;  // chain steps between two lo
 // REFILL_MIN: idle lanes a wave waits for before it fetches new positions.  1 (levels 4-6): every
 // round, with no branch around the refill.  At max_chain 256 and more a round ends only about four
 // walks, and running the refill for them every round costs more than letting them wait.
-template <bool HAS_DICT, int REFILL_MIN>
-__global__ __launch_bounds__(kMatchThreads) void k_match_lazy(Batch B, uint32_t tiles_per_stream) {
+// THREADS: 1024, or 256 for batches of short streams (a 4 KiB stream gives 1024 lanes four positions each, most of
+// them spent in the drain at the tile's end; with its few KB of LDS eight of the small workgroups share a CU).
+// lds_byte_cap: bytes of LDS set aside for the staged bytes (a multiple of 4); the links follow them.
+template <bool HAS_DICT, int REFILL_MIN, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_per_stream, uint32_t lds_byte_cap) {
+  constexpr int kMatchThreads = THREADS;
   extern __shared__ uint32_t smem[];
-  uint32_t *lbytes = smem;                                 // kLdsByteCap bytes
-  uint16_t *lprev = (uint16_t *)(smem + kLdsByteCap / 4);  // kLdsPrevCap entries
+  uint32_t *lbytes = smem;                                  // lds_byte_cap bytes
+  uint16_t *lprev = (uint16_t *)(smem + lds_byte_cap / 4);  // window + tile + 8 entries
   __shared__ uint32_t s_next;
 
   const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);

@@ -297,8 +297,9 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   if (!cx.attr_done) {
     HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true, kSortThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(kSortLdsMaxV)));
-    for (const void *f : {(const void *)k_match_lazy<false, 1>, (const void *)k_match_lazy<true, 1>,
-                          (const void *)k_match_lazy<false, kRefillMinDeep>, (const void *)k_match_lazy<true, kRefillMinDeep>})
+    for (const void *f : {(const void *)k_match_lazy<false, 1, kMatchThreads>, (const void *)k_match_lazy<true, 1, kMatchThreads>,
+                          (const void *)k_match_lazy<false, kRefillMinDeep, kMatchThreads>,
+                          (const void *)k_match_lazy<true, kRefillMinDeep, kMatchThreads>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     cx.attr_done = true;
   }
@@ -367,10 +368,21 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
       } else if (level_cfg(level).lazy) {
         const uint32_t tiles = (uint32_t)((max_in_len + kTile - 1) / kTile);
         const bool deep = level_cfg(level).max_chain >= 256;
-        if (tiles && vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, 1>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
-        if (tiles && !vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, 1>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
-        if (tiles && vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
-        if (tiles && !vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles);
+        if (tiles && (size_t)vd + max_in_len <= kMatchNarrowMaxV) {
+          // short streams: one tile is the whole stream; small workgroups, LDS sized to the longest stream
+          const uint32_t cap = (uint32_t)round_up((size_t)vd + max_in_len + 288 + 16, 16);
+          const uint32_t lds = cap + 2 * (uint32_t)(vd + max_in_len + 8);
+          if (vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, 1, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap);
+          if (!vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, 1, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap);
+          if (vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap);
+          if (!vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap);
+        } else if (tiles) {
+          const uint32_t cap = kLdsByteCap;
+          if (vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, 1, kMatchThreads>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles, cap);
+          if (!vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, 1, kMatchThreads>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles, cap);
+          if (vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep, kMatchThreads>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles, cap);
+          if (!vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep, kMatchThreads>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles, cap);
+        }
         LAUNCH("k_parse_lazy", k_parse_lazy, c * max_blocks, kParseThreads, 0, B);
       } else {
         LAUNCH("k_lz_greedy", k_lz_greedy, c, kWave, 0, B);

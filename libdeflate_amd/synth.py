@@ -90,3 +90,26 @@ def addon_streams(count, length=4096, first_stream=0):
         buf = b"".join(parts)[: length - 4] + b"^t^^"
         out[s] = np.frombuffer(buf, dtype=np.uint8)
     return out
+
+
+def addon_record_pool(nrec=16384):
+    """A pool of G-addon records (the same two record kinds as addon_streams) for the device-side generator of
+    bench.py, which draws records from it with a Zipf law: item strings repeat the way they do in addon data."""
+    rng = np.random.Generator(np.random.PCG64(SEED ^ 0xADD1))
+    pool = np.random.Generator(np.random.PCG64(SEED ^ 0xADD0)).integers(100000, 200000, 2000)
+    zipf = (np.arange(1, 2001, dtype=np.float64)) ** -1.1
+    cdf = np.cumsum(zipf / zipf.sum())
+    u = rng.random((nrec, 3))
+    ids = pool[np.minimum(np.searchsorted(cdf, u[:, 1]), 1999)]
+    ench = np.where(u[:, 2] < 0.3, rng.integers(0, 6000, nrec), 0)
+    bonus = rng.integers(1400, 3600, (nrec, 3))
+    keyi = rng.integers(0, len(_KEYS), nrec)
+    keyn = rng.integers(0, 4, nrec)
+    val = rng.integers(0, 100000, nrec)
+    recs = []
+    for i in range(nrec):
+        if u[i, 0] < 0.6:
+            recs.append(b"^Sitem:%d:%d::::::::110:::%d:%d:%d" % (ids[i], ench[i], bonus[i, 0], bonus[i, 1], bonus[i, 2]))
+        else:
+            recs.append(b"^S" + _KEYS[keyi[i]] + b"%d^N%d" % (keyn[i], val[i]))
+    return recs

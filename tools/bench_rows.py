@@ -1,0 +1,322 @@
+"""Secondary, verified entries of bench.py's JSON line (outside the timed headline): the other BASELINE.json configs
+measured the same way -- device-resident, kernel time from HIP events on the library's stream, every result checked.
+
+    configs[1]  65 536 x 4 KiB addon-style strings, levels 1 / 5 / 8
+    configs[3]  CompressZlib + preset 32 KiB dictionary (with the Adler-32 kernel), 128 KiB text streams
+    configs[4]  "C5" of SURVEY 8.d: mixed streams (raw / zlib, levels 1 / 5 / 8, 5 % stored, 5 % made by zlib itself)
+                through DecodeForPrint -> DecompressDeflate / DecompressZlib, and EncodeForPrint of the streams
+    host API    the PCIe-inclusive rate of the host-pointer batch calls (never the headline value)
+
+Each entry carries its own roofline: algorithmic bytes / kernel time / 8 TB/s.
+torch is plumbing here (device buffers, comparisons); everything measured is libdeflate_hip.so.  Measurement
+infrastructure like bench.py itself (not part of the product package); the oracle, where used, is handed in by bench.py
+as the checker.
+"""
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+from libdeflate_amd import _native as N
+from libdeflate_amd import batch as B
+from libdeflate_amd import synth
+
+HBM_PEAK_GBS = 8000.0
+
+
+def gen_addon_device(torch, count, length, device, seed):
+    """G-addon on the device: every stream is '^1^T' + records drawn with a Zipf(1.1) law from a pool of
+    16 384 AceSerializer-style records (synth.addon_record_pool: item strings over a 2 000-id pool, key/number pairs)
+    cut to exactly `length` bytes, ending in '^t^^'.  Returns uint8 tensor (count * length)."""
+    recs = synth.addon_record_pool()
+    R, W = len(recs), max(len(r) for r in recs)
+    table = np.zeros((R, W), dtype=np.uint8)
+    lens = np.zeros(R, dtype=np.int64)
+    for i, r in enumerate(recs):
+        table[i, : len(r)] = np.frombuffer(r, dtype=np.uint8)
+        lens[i] = len(r)
+    t_table = torch.from_numpy(table).to(device)
+    t_lens = torch.from_numpy(lens).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed((seed ^ 0xADD0) & 0x7FFFFFFFFFFFFFFF)
+    p = torch.arange(1, R + 1, dtype=torch.float64, device=device) ** -1.1
+    cdf = torch.cumsum(p / p.sum(), 0).to(torch.float32)
+    K = length // int(lens.min()) + 2
+    out = torch.empty(count * length, dtype=torch.uint8, device=device)
+    j = torch.arange(length, device=device)
+    step = 4096
+    for s0 in range(0, count, step):
+        n = min(step, count - s0)
+        idx = torch.searchsorted(cdf, torch.rand(n, K, device=device, generator=g)).clamp_(max=R - 1)
+        l = t_lens[idx]
+        cum = torch.cumsum(l, 1)
+        q = j[None, :].expand(n, length).contiguous()
+        r = torch.searchsorted(cum, q, right=True)
+        start = torch.gather(cum - l, 1, r)
+        out[s0 * length: (s0 + n) * length] = t_table[torch.gather(idx, 1, r), q - start].reshape(-1)
+    v = out.view(count, length)
+    v[:, :4] = torch.tensor(list(b"^1^T"), dtype=torch.uint8, device=device)
+    v[:, -4:] = torch.tensor(list(b"^t^^"), dtype=torch.uint8, device=device)
+    return out
+
+
+def _profiled(fn, torch, reps=2):
+    """Kernel milliseconds by name of the last of `reps` runs of fn."""
+    torch.cuda.synchronize()
+    pr = {}
+    for _ in range(reps):
+        B.profile(True)
+        B.profile_reset()
+        fn()
+        B.sync()
+        pr = B.profile_report()
+        B.profile(False)
+    return {k: v[0] for k, v in pr.items()}
+
+
+def _roofline(alg_bytes, ms):
+    ach = alg_bytes / 1e6 / max(ms, 1e-9)
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "algorithmic_bytes": int(alg_bytes), "kernel_ms": ms}
+
+
+def _slots_equal(torch, slots, stride, lens, rows, want):
+    """slots[rows[i]] holds exactly the bytes `want[i]` (checker for a handful of streams)."""
+    lens_h = lens.cpu().numpy()
+    for r, w in zip(rows, want):
+        got = slots[r * stride: r * stride + int(lens_h[r])].cpu().numpy().tobytes()
+        if got != w:
+            return False
+    return True
+
+
+def row_small_strings(torch, dev, seed, count=65536, length=4096, levels=(1, 5, 8), T=None):
+    """BASELINE configs[1]: `count` x `length` addon-style strings, round trip per level.
+    T: the test oracle binding (tests/ldtest.py), used as the checker on a sample; None skips that check."""
+    data = gen_addon_device(torch, count, length, dev, seed)
+    off = torch.arange(count + 1, dtype=torch.int64, device=dev) * length
+    bt = B.DeviceBatch(data, off, length)
+    stride = N.lib.ldh_compress_bound(length)
+    comp = torch.empty(count * stride, dtype=torch.uint8, device=dev)
+    clen = torch.zeros(count, dtype=torch.int32, device=dev)
+    pad = torch.zeros(count, dtype=torch.uint8, device=dev)
+    back = torch.empty(count * length, dtype=torch.uint8, device=dev)
+    blen = torch.zeros(count, dtype=torch.int32, device=dev)
+    left = torch.zeros(count, dtype=torch.int32, device=dev)
+    status = torch.zeros(count, dtype=torch.int32, device=dev)
+    sample = [0, 1, count // 2, count - 1]
+    rows_h = [data[i * length: (i + 1) * length].cpu().numpy().tobytes() for i in sample] if T else []
+    out = {"workload": "%d x %d B G-addon strings (SURVEY 8.d), CompressDeflate + DecompressDeflate, device-resident" % (count, length),
+           "levels": {}}
+    nbytes = count * length
+    for level in levels:
+        def step():
+            B.device_compress(bt, comp, stride, clen, pad, fmt=0, level=level)
+            B.device_decompress_slots(comp, stride, clen, count, back, length, blen, left, status, fmt=0)
+        pr = _profiled(step, torch)
+        t_d = pr.get("k_inflate", 0.0)
+        t_c = sum(pr.values()) - t_d
+        cbytes = int(clen.sum().item())
+        ok = bool(torch.equal(back, data)) and int(status.abs().sum()) == 0 and int(left.sum()) == 0
+        if T:
+            ok = ok and _slots_equal(torch, comp, stride, clen, sample, [T.o_compress(r, level=level)[0] for r in rows_h])
+        name = max(pr, key=pr.get)
+        out["levels"][str(level)] = {
+            "roundtrip_GBps": nbytes / 1e6 / (t_c + t_d), "compress_GBps": nbytes / 1e6 / t_c, "decompress_GBps": nbytes / 1e6 / t_d,
+            "compress_ratio": nbytes / max(cbytes, 1), "verified": ok, "kernel_ms": {k: round(v, 3) for k, v in sorted(pr.items())},
+            "roofline": dict(_roofline(nbytes + cbytes, pr[name]), kernel=name)}
+    return out
+
+
+def row_zlib_dictionary(torch, dev, data, count, length, dict_path, level=5, T=None):
+    """BASELINE configs[3]: CompressZlibWithDict / DecompressZlibWithDict with the reference's 32 KiB preset dictionary
+    (a copy of tests/dictionary32768.txt is kept as a golden fixture), Adler-32 kernel included."""
+    from libdeflate_amd.LibDeflate import LibDeflate
+    dct = open(dict_path, "rb").read()
+    d = LibDeflate.CreateDictionary(dct, len(dct), LibDeflate.Adler32(dct))
+    sub = data[: count * length]
+    off = torch.arange(count + 1, dtype=torch.int64, device=dev) * length
+    bt = B.DeviceBatch(sub, off, length)
+    stride = N.lib.ldh_compress_bound(length)
+    comp = torch.empty(count * stride, dtype=torch.uint8, device=dev)
+    clen = torch.zeros(count, dtype=torch.int32, device=dev)
+    pad = torch.zeros(count, dtype=torch.uint8, device=dev)
+    back = torch.empty(count * length, dtype=torch.uint8, device=dev)
+    blen = torch.zeros(count, dtype=torch.int32, device=dev)
+    left = torch.zeros(count, dtype=torch.int32, device=dev)
+    status = torch.zeros(count, dtype=torch.int32, device=dev)
+    prc = _profiled(lambda: B.device_compress(bt, comp, stride, clen, pad, fmt=1, level=level, dictionary=d), torch)
+    prd = _profiled(lambda: B.device_decompress_slots(comp, stride, clen, count, back, length, blen, left, status, fmt=1,
+                                                      dictionary=d), torch)
+    nbytes, cbytes = count * length, int(clen.sum().item())
+    ok = bool(torch.equal(back, sub)) and int(status.abs().sum()) == 0 and int(left.sum()) == 0
+    if T:
+        sample = [0, count - 1]
+        rows_h = [sub[i * length: (i + 1) * length].cpu().numpy().tobytes() for i in sample]
+        ok = ok and _slots_equal(torch, comp, stride, clen, sample,
+                                 [T.o_compress(r, zlib=True, level=level, dict=dct)[0] for r in rows_h])
+    t_c, t_d = sum(prc.values()), sum(prd.values())
+    name = max(prc, key=prc.get)
+    return {"workload": "%d x %d B G-text streams, CompressZlibWithDict(level %d) + DecompressZlibWithDict, 32768-byte preset "
+                        "dictionary, device-resident" % (count, length, level),
+            "compress_GBps": nbytes / 1e6 / t_c, "decompress_GBps": nbytes / 1e6 / t_d, "roundtrip_GBps": nbytes / 1e6 / (t_c + t_d),
+            "adler32_GBps": nbytes / 1e6 / max(prc.get("k_adler32", 0.0), 1e-9), "compress_ratio": nbytes / max(cbytes, 1),
+            "verified": ok, "kernel_ms": {"compress": {k: round(v, 3) for k, v in sorted(prc.items())},
+                                          "decompress": {k: round(v, 3) for k, v in sorted(prd.items())}},
+            "roofline": dict(_roofline(nbytes + cbytes, prc[name]), kernel=name)}
+
+
+def c5_plan(count):
+    """Deterministic make-up of the C5 batch: per stream (level, fmt, foreign).  5 % stored (level 0),
+    5 % made by zlib itself, the rest levels 1 / 5 / 8 in turn; raw deflate and zlib framing alternate."""
+    plan = []
+    for i in range(count):
+        fmt = (i // 20 + i) % 2
+        if i % 20 == 0:
+            plan.append((0, fmt, False))
+        elif i % 20 == 1:
+            plan.append((6, fmt, True))
+        else:
+            plan.append(((1, 5, 8)[i % 3], fmt, False))
+    return plan
+
+
+def row_mixed_inflate_print(torch, dev, data, count, length):
+    """BASELINE configs[4] / C5: DecodeForPrint -> DecompressDeflate / DecompressZlib over a mixed batch, plus
+    EncodeForPrint of the compressed streams (what a WoW caller sends and receives)."""
+    from concurrent.futures import ThreadPoolExecutor
+    rows = data[: count * length].view(count, length)
+    stride = N.lib.ldh_compress_bound(length)
+    slots = torch.zeros(count * stride, dtype=torch.uint8, device=dev)
+    clen = torch.zeros(count, dtype=torch.int32, device=dev)
+    plan = c5_plan(count)
+    groups = {}
+    for i, (lv, fmt, foreign) in enumerate(plan):
+        groups.setdefault((lv, fmt, foreign), []).append(i)
+    for (lv, fmt, foreign), idx in sorted(groups.items()):
+        sel = torch.tensor(idx, dtype=torch.int64, device=dev)
+        if foreign:  # streams made by zlib 1.2.11 itself (the reference's tests use its zdeflate helper for these)
+            host = rows[sel].cpu().numpy()
+
+            def z(r):
+                co = zlib.compressobj(lv, zlib.DEFLATED, 15 if fmt else -15)
+                return co.compress(r.tobytes()) + co.flush()
+            with ThreadPoolExecutor(max_workers=8) as ex:
+                made = list(ex.map(z, host))
+            buf = np.zeros((len(idx), stride), dtype=np.uint8)
+            for k, m in enumerate(made):
+                buf[k, : len(m)] = np.frombuffer(m, dtype=np.uint8)
+            slots.view(count, stride)[sel] = torch.from_numpy(buf).to(dev)
+            clen[sel] = torch.tensor([len(m) for m in made], dtype=torch.int32, device=dev)
+            continue
+        sub = rows[sel].contiguous().view(-1)
+        n = len(idx)
+        off = torch.arange(n + 1, dtype=torch.int64, device=dev) * length
+        c = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+        cl = torch.zeros(n, dtype=torch.int32, device=dev)
+        pd = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        B.device_compress(B.DeviceBatch(sub, off, length), c, stride, cl, pd, fmt=fmt, level=lv)
+        B.sync()
+        slots.view(count, stride)[sel] = c.view(n, stride)
+        clen[sel] = cl
+    # the streams back to back (what EncodeForPrint takes), their print form, and the way back
+    lens = clen.to(torch.int64)
+    coff = torch.zeros(count + 1, dtype=torch.int64, device=dev)
+    coff[1:] = torch.cumsum(lens, 0)
+    cbytes = int(coff[-1].item())
+    packed = slots.view(count, stride)[torch.arange(stride, device=dev)[None, :] < lens[:, None]].contiguous()
+    pstride = ((int(lens.max().item()) * 8 + 5) // 6 + 31) // 16 * 16
+    text = torch.empty(count * pstride, dtype=torch.uint8, device=dev)
+    tlen = torch.zeros(count, dtype=torch.int32, device=dev)
+    pr_enc = _profiled(lambda: N.check(N.lib.ldh_print6_encode_batch_dev(packed.data_ptr(), coff.data_ptr(), count, text.data_ptr(),
+                                                                        pstride, tlen.data_ptr())), torch)
+    tl = tlen.to(torch.int64)
+    toff = torch.zeros(count + 1, dtype=torch.int64, device=dev)
+    toff[1:] = torch.cumsum(tl, 0)
+    tbytes = int(toff[-1].item())
+    tpacked = text.view(count, pstride)[torch.arange(pstride, device=dev)[None, :] < tl[:, None]].contiguous()
+    del text
+    dec = torch.zeros(count * stride, dtype=torch.uint8, device=dev)  # DecodeForPrint lands in decompress's input slots
+    dlen = torch.zeros(count, dtype=torch.int32, device=dev)
+    dok = torch.zeros(count, dtype=torch.uint8, device=dev)
+    pr_dec = _profiled(lambda: N.check(N.lib.ldh_print6_decode_batch_dev(tpacked.data_ptr(), toff.data_ptr(), count, dec.data_ptr(),
+                                                                        stride, dlen.data_ptr(), dok.data_ptr())), torch)
+    ok = bool(torch.equal(dlen, clen)) and int(dok.sum().item()) == count
+    same = dec.view(count, stride)[torch.arange(stride, device=dev)[None, :] < lens[:, None]]
+    ok = ok and bool(torch.equal(same, packed))
+    del same, tpacked, packed
+    # inflate: one call per framing, straight from the slots DecodeForPrint filled
+    back = torch.empty(count * length, dtype=torch.uint8, device=dev)
+    blen = torch.zeros(count, dtype=torch.int32, device=dev)
+    left = torch.zeros(count, dtype=torch.int32, device=dev)
+    status = torch.zeros(count, dtype=torch.int32, device=dev)
+    per_fmt = {}
+    for fmt in (0, 1):
+        idx = [i for i, pl in enumerate(plan) if pl[1] == fmt]
+        sel = torch.tensor(idx, dtype=torch.int64, device=dev)
+        n = len(idx)
+        s_in = dec.view(count, stride)[sel].contiguous().view(-1)
+        s_len = dlen[sel].contiguous()
+        o = torch.empty(n * length, dtype=torch.uint8, device=dev)
+        ol = torch.zeros(n, dtype=torch.int32, device=dev)
+        lf = torch.zeros(n, dtype=torch.int32, device=dev)
+        st = torch.full((n,), 99, dtype=torch.int32, device=dev)
+        per_fmt[fmt] = _profiled(lambda: B.device_decompress_slots(s_in, stride, s_len, n, o, length, ol, lf, st, fmt=fmt), torch)
+        back.view(count, length)[sel] = o.view(n, length)
+        blen[sel], left[sel], status[sel] = ol, lf, st
+    ok = ok and bool(torch.equal(back.view(count, length), rows)) and int(status.abs().sum()) == 0 and int(left.sum()) == 0
+    ok = ok and bool((blen == length).all())
+    nbytes = count * length
+    t_inf = sum(sum(v.values()) for v in per_fmt.values())
+    t_enc, t_dec = sum(pr_enc.values()), sum(pr_dec.values())
+    return {"workload": "%d mixed streams of %d B uncompressed (50%% raw / 50%% zlib; levels 1/5/8, 5%% stored, 5%% made by zlib "
+                        "1.2.11 at level 6): EncodeForPrint of the streams, DecodeForPrint, DecompressDeflate / DecompressZlib; "
+                        "device-resident" % (count, length),
+            "uncompressed_bytes": nbytes, "compressed_bytes": cbytes, "print_bytes": tbytes, "verified": ok,
+            "decompress_GBps_of_output": nbytes / 1e6 / t_inf, "print_encode_GBps_of_input": cbytes / 1e6 / t_enc,
+            "print_decode_GBps_of_output": cbytes / 1e6 / t_dec,
+            "decode_then_decompress_GBps_of_output": nbytes / 1e6 / (t_inf + t_dec),
+            "kernel_ms": {"print6_encode": round(t_enc, 3), "print6_decode": round(t_dec, 3),
+                          "inflate_raw": {k: round(v, 3) for k, v in sorted(per_fmt[0].items())},
+                          "inflate_zlib": {k: round(v, 3) for k, v in sorted(per_fmt[1].items())}},
+            "roofline": {"decompress": dict(_roofline(cbytes + nbytes, t_inf), kernel="k_inflate (+ k_adler32, k_zlib_check)"),
+                         "print6_encode": dict(_roofline(cbytes + tbytes, t_enc), kernel="k_print6_encode"),
+                         "print6_decode": dict(_roofline(cbytes + tbytes, t_dec), kernel="k_print6_decode")}}
+
+
+def row_host_api(torch, data, count, length, level=5):
+    """The path a Lua / Python caller takes: host-pointer batch calls on ordinary pageable memory, transfers included.
+    A labelled secondary number; never the headline value."""
+    host = data[: count * length].cpu().numpy()
+    off = (np.arange(count + 1, dtype=np.uint64) * np.uint64(length))
+    stride = N.lib.ldh_compress_bound(length)
+    out = np.empty(count * stride, dtype=np.uint8)
+    out_len = np.zeros(count, dtype=np.uint32)
+    pad = np.zeros(count, dtype=np.uint8)
+    back = np.empty(count * length, dtype=np.uint8)
+    back_len = np.zeros(count, dtype=np.uint32)
+    left = np.zeros(count, dtype=np.uint32)
+    status = np.zeros(count, dtype=np.int32)
+    best_c = best_d = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        N.check(N.lib.ldh_compress_batch(host.ctypes.data, off.ctypes.data, count, 0, level, 0, None, out.ctypes.data, stride,
+                                         out_len.ctypes.data, pad.ctypes.data))
+        best_c = min(best_c, time.perf_counter() - t0)
+    coff = np.zeros(count + 1, dtype=np.uint64)
+    np.cumsum(out_len, out=coff[1:])
+    packed = np.concatenate([out[i * stride: i * stride + int(out_len[i])] for i in range(count)])
+    for _ in range(2):
+        t0 = time.perf_counter()
+        N.check(N.lib.ldh_decompress_batch(packed.ctypes.data, coff.ctypes.data, count, 0, None, back.ctypes.data, length,
+                                           back_len.ctypes.data, left.ctypes.data, status.ctypes.data))
+        best_d = min(best_d, time.perf_counter() - t0)
+    ok = bool(np.array_equal(back, host)) and not status.any() and not left.any()
+    nbytes = count * length
+    return {"workload": "%d x %d B G-text streams in pageable host memory, ldh_compress_batch(level %d) + ldh_decompress_batch, "
+                        "PCIe transfers and host staging included" % (count, length, level),
+            "compress_GBps": nbytes / 1e9 / best_c, "decompress_GBps": nbytes / 1e9 / best_d,
+            "roundtrip_GBps": nbytes / 1e9 / (best_c + best_d), "verified": ok}

@@ -10,7 +10,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() { # name, timeout, rocprof args...
   local name=$1 to=$2; shift 2
-  timeout -s KILL "$to" rocprofv3 "$@" --output-format csv -d "$out/prof_${tag}_$name" -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-levels > "$out/${tag}_$name.log" 2>&1
+  timeout -s KILL "$to" rocprofv3 "$@" --output-format csv -d "$out/prof_${tag}_$name" -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-levels --no-extra-rows > "$out/${tag}_$name.log" 2>&1
   local rc=$?
   echo "$name rc=$rc"
   return $rc
