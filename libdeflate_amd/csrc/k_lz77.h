@@ -126,8 +126,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
   uint32_t *bufB = B.sortB + (size_t)blockIdx.x * B.sort_stride;
   uint16_t *prevd = B.prevd + (size_t)s * B.nvp + lo;
   // where the sorted array ends up; greedy levels also get its inverse (rank of a position)
-  // (greedy levels: entries of the final array carry the first four bytes of their position too)
-  uint2 *srt2 = B.want_rank ? (uint2 *)B.bufC + (size_t)s * B.nvp : nullptr;
+  // (greedy levels: entries of the final array carry the first twelve bytes of their position too)
+  uint4 *srt2 = B.want_rank ? (uint4 *)B.bufC + (size_t)s * B.nvp : nullptr;
   uint32_t *rank = bufB;
 #define SRT(r) (B.want_rank ? srt2[(r)].x : bufA[(r)])
 #define VBYTE(i) (V_LDS ? (uint32_t)ldsV[(i)] : (uint32_t)V[(i)])
@@ -254,9 +254,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
         if (e[j] != 0xFFFFFFFFu) {
           const uint32_t at = s_bprev[d[j]] + s_pre[wave][d[j]] + lrank[j];
           if (pass == 2 && B.want_rank) {
-            const uint32_t w4 = V_LDS ? lds_load4((const uint32_t *)ldsV, e[j])
-                                      : VBYTE(e[j]) | (VBYTE(e[j] + 1) << 8) | (VBYTE(e[j] + 2) << 16) | (VBYTE(e[j] + 3) << 24);
-            srt2[at] = make_uint2(e[j], w4);
+            uint32_t w4[3];
+#pragma unroll
+            for (uint32_t q = 0; q < 3; q++) {
+              const uint32_t o = e[j] + 4 * q;  // (V is zero padded: kVPad bytes)
+              w4[q] = V_LDS ? lds_load4((const uint32_t *)ldsV, o)
+                            : VBYTE(o) | (VBYTE(o + 1) << 8) | (VBYTE(o + 2) << 16) | (VBYTE(o + 3) << 24);
+            }
+            srt2[at] = make_uint4(e[j], w4[0], w4[1], w4[2]);
             if (V_LDS) dst[at] = e[j];  // (the compact copy the un-sort below reads)
           } else {
             dst[at] = e[j];
@@ -808,21 +813,36 @@ __device__ inline uint32_t gld4(const uint8_t *V, uint32_t off) {  // V is 16-by
   return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3);
 }
 
-// The walk is bound by memory latency (two to three dependent round trips per token), so what
-// counts is how many streams a CU keeps in flight: a ring of 40960 positions (window + longest
-// match + slack; 5 KB) and 64 VGPRs let 8 wavefronts per SIMD be resident.
+// One wavefront per stream.  A 128 KiB stream has some 30000 tokens and a token costs the dependent round trips to
+// global memory it makes (the sorted arrays of 8192 streams are 17 GB: every fetch is a miss), so a token is built to
+// need ONE round trip in the usual case:
+//  * the rank and first bytes of the next 32 positions are fetched while the current position is being worked on,
+//    so the next position (x + token length) starts without a round trip of its own;
+//  * an entry of the sorted array carries the first twelve bytes of its position, so a candidate's length is known
+//    from the fetch that found it unless it reaches twelve (then the whole wave compares the next 256 bytes of that
+//    one candidate at once: one more round trip, whatever the length);
+//  * level 1 fetches 16 candidates per trip (it wants 4 inserted ones), level 2 32, level 3 64.
+// Measured alternatives (all byte-identical, none faster; ms per GiB at level 1 against 79 for this one): four
+// streams per wavefront, sixteen lanes each, to quarter the instructions per token (89: the 5 KB "was inserted" ring
+// per stream leaves eight such wavefronts per CU, too few to hide the round trips), two streams of 32 lanes (88),
+// fetches of whole 128-byte lines of the sorted array (93: fewer candidates per trip, more trips).  The walk is bound by
+// the loaded latency of its scattered reads (169 GB of 128-byte misses per GiB of input, 1.9 TB/s).
+// What counts besides is how many streams a CU keeps in flight: a ring of 40960 positions (window + longest match +
+// slack; 5 KB) and 64 VGPRs let 8 wavefronts per SIMD be resident.
 constexpr uint32_t kInsWords = 1280;
+constexpr uint32_t kGreedyAhead = 32;  // positions fetched ahead
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz_greedy(Batch B) {
   __shared__ uint32_t s_ins[kInsWords];  // bit (q mod 40960): stream position q is in a hash chain (LD:1347)
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= B.count) return;
   const uint32_t n = stream_len(B, s), D = B.dlen;
   const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
-  const uint2 *sorted = (const uint2 *)B.bufC + (size_t)s * B.nvp;  // {position, its first four bytes}
+  const uint4 *sorted = (const uint4 *)B.bufC + (size_t)s * B.nvp;  // {position, its first twelve bytes}
   const uint32_t *rank = B.bufB + (size_t)s * B.nvp;
   const LevelCfg cfg = level_cfg(B.level);
   const uint32_t nice = (uint32_t)cfg.nice, max_chain = (uint32_t)cfg.max_chain;
   const uint32_t max_insert = (uint32_t)cfg.max_lazy;  // max_insert_length for these levels
+  const uint32_t W = max_chain <= 4 ? 16u : (max_chain <= 8 ? 32u : 64u);  // candidates fetched per trip
   const uint32_t nblk = num_blocks(n);
   const unsigned long long below = (1ull << lane) - 1ull;
   for (uint32_t i = lane; i < kInsWords; i += kWave) s_ins[i] = 0;
@@ -832,33 +852,32 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t bs = block_start(b), be = block_end(b, n);  // 1-based, inclusive
     uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
     uint32_t ntok = 0, x = bs - 1;  // x: 0-based stream position
-    // rank and first four bytes of the current position; those of the 64 positions after it
-    // are fetched while it is being worked on, so that the next position (x + token length)
-    // usually starts without a memory round trip
     uint32_t cur_r = __builtin_amdgcn_readfirstlane(rank[x + D]);
-    uint32_t cur_w = __builtin_amdgcn_readfirstlane(gld4(V, x + D));
+    uint32_t my0 = __builtin_amdgcn_readfirstlane(gld4(V, x + D));
+    uint32_t my1 = __builtin_amdgcn_readfirstlane(gld4(V, x + D + 4));
+    uint32_t my2 = __builtin_amdgcn_readfirstlane(gld4(V, x + D + 8));
     while (x + 1 <= be) {
       const uint32_t v = x + D;
-      const uint32_t my = cur_w;
-      const uint32_t pv = v + 1 + lane < D + n ? v + 1 + lane : D + n - 1;
+      // lanes 32.. repeat the addresses of lanes 0..31: no further memory transactions
+      const uint32_t pv = v + 1 + (lane & (kGreedyAhead - 1)) < D + n ? v + 1 + (lane & (kGreedyAhead - 1)) : D + n - 1;
       const uint32_t pre_r = rank[pv], pre_w = gld4(V, pv);
       uint32_t best = 0, bdist = 0;
       if (x + 3 <= be) {  // LD:1349
         uint32_t maxlen = be - x;
         if (maxlen > kMaxMatch) maxlen = kMaxMatch;
-        const uint32_t key = my & 0xFFFFFFu;
+        const uint32_t key = my0 & 0xFFFFFFu;
         const uint32_t r = cur_r;
         uint32_t taken = 0;
         bool seen_seed = false;
-        for (uint32_t base = 0;; base += kWave) {
-          const bool have = r >= 1 + base + lane;
-          uint2 ce = make_uint2(0u, ~my);
+        for (uint32_t base = 0;; base += W) {
+          const bool have = (lane < W) & (r >= 1 + base + lane);
+          uint4 ce = make_uint4(0u, ~my0, 0u, 0u);
           if (have) ce = sorted[r - 1 - base - lane];
-          const uint32_t c = ce.x, cw = ce.y;
-          const bool ok = have && (cw & 0xFFFFFFu) == key && v - c <= kWindow;  // (another group's c may exceed v)
+          const uint32_t c = ce.x;
+          const bool ok = have && (ce.y & 0xFFFFFFu) == key && v - c <= kWindow;  // (another group's c may exceed v)
           // the chain is the run of ok lanes from lane 0
           const unsigned long long notok = ~ballot64(ok);
-          const uint32_t first_bad = notok ? (uint32_t)__builtin_ctzll(notok) : 64u;
+          const uint32_t first_bad = notok ? (uint32_t)__builtin_ctzll(notok) : 64u;  // (<= W)
           const bool in_chain = lane < first_bad;
           const bool in_dict = c < D, deep = in_dict && c + 2 < D;
           unsigned long long seedm = 0;
@@ -874,23 +893,37 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           const bool cand = in_chain && lane < first_brk && inserted;
           const unsigned long long candm = ballot64(cand);
           const bool sel = cand && taken + (uint32_t)__popcll(candm & below) < max_chain;  // LD:1362
+          // length from the entry's twelve bytes (the trigram is known to be equal)
           uint32_t L = 0;
           if (sel) {
-            L = 3;
-            if ((cw >> 24) == (my >> 24)) {
-              L = 4;
-              while (L < maxlen) {
-                const uint32_t y = gld4(V, c + L) ^ gld4(V, v + L);
-                if (y) {
-                  L += __builtin_ctz(y) >> 3;
-                  break;
-                }
-                L += 4;
-              }
-            }
-            if (L > maxlen) L = maxlen;
+            const uint32_t x0 = ce.y ^ my0, x1 = ce.z ^ my1, x2 = ce.w ^ my2;
+            L = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : (x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : (x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : 12u));
+            if (L > maxlen) L = maxlen;  // LD:1356-1359: a match never crosses the block's end
           }
           const unsigned long long selm = ballot64(sel);
+          // candidates that reached twelve bytes get their true length from the whole wave, nearest first, until one
+          // reaches nice_length (the walk would have stopped there, LD:1389: the ones behind it do not matter)
+          unsigned long long lm = ballot64(sel && L >= 12 && maxlen > 12);
+          if (nice <= 12) {  // (uniform) the first candidate of 8 (level 1) ends the walk whatever its true length
+            const unsigned long long n12 = ballot64(sel && L >= nice);
+            if (n12) lm &= (n12 & (0ull - n12)) | ((n12 & (0ull - n12)) - 1ull);
+          }
+          while (lm) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(lm);
+            lm &= lm - 1;
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+            const uint32_t off = 12 + 4 * lane;  // (12 + 4 * 63 > 258: some lane always ends the comparison)
+            uint32_t y = 1;
+            if (off < maxlen) y = gld4(V, cj + off) ^ gld4(V, v + off);
+            const unsigned long long mism = ballot64(y != 0);
+            const uint32_t f = (uint32_t)__builtin_ctzll(mism);
+            const uint32_t yf = __builtin_amdgcn_readlane(y, f);
+            uint32_t Lj = 12 + 4 * f;
+            if (Lj < maxlen) Lj += (uint32_t)__builtin_ctz(yf) >> 3;  // (a lane at or beyond maxlen holds y = 1: + 0)
+            if (Lj > maxlen) Lj = maxlen;
+            L = lane == j ? Lj : L;
+            if (Lj >= nice) lm = 0;
+          }
           // nice_length: the walk stops at the nearest candidate that reaches it (LD:1389)
           const unsigned long long nicem = ballot64(sel && L >= nice);
           const uint32_t first_nice = nicem ? (uint32_t)__builtin_ctzll(nicem) : 64u;
@@ -916,7 +949,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           }
           taken += (uint32_t)__popcll(selm);
           seen_seed = seen_seed || seedm != 0;
-          if (nicem || first_bad < 64 || first_brk < 64 || taken >= max_chain) break;
+          if (nicem || first_bad < W || first_brk < 64 || taken >= max_chain) break;
         }
       }
       // ---- the token, and which of its positions enter the chains
@@ -927,7 +960,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         len = best;
         interior_on = best <= max_insert;  // LD:1454
       } else {
-        if (lane == 0) tok[ntok] = my & 0xFFu;
+        if (lane == 0) tok[ntok] = my0 & 0xFFu;
       }
       ntok++;
       {
@@ -943,12 +976,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       }
       __syncthreads();
       x += len;
-      if (len <= kWave) {
+      if (len + 8 <= kGreedyAhead) {  // the new position's rank and twelve bytes are among what was fetched ahead
         cur_r = __builtin_amdgcn_readlane(pre_r, len - 1);
-        cur_w = __builtin_amdgcn_readlane(pre_w, len - 1);
+        my0 = __builtin_amdgcn_readlane(pre_w, len - 1);
+        my1 = __builtin_amdgcn_readlane(pre_w, len + 3);
+        my2 = __builtin_amdgcn_readlane(pre_w, len + 7);
       } else if (x < n) {
         cur_r = __builtin_amdgcn_readfirstlane(rank[x + D]);
-        cur_w = __builtin_amdgcn_readfirstlane(gld4(V, x + D));
+        my0 = __builtin_amdgcn_readfirstlane(gld4(V, x + D));
+        my1 = __builtin_amdgcn_readfirstlane(gld4(V, x + D + 4));
+        my2 = __builtin_amdgcn_readfirstlane(gld4(V, x + D + 8));
       }
     }
     if (lane == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;

@@ -274,7 +274,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
   const uint32_t segs = (!sort_in_lds && need_lz && !greedy) ? (uint32_t)((vd + max_in_len + kSegOut - 1) / kSegOut) : 1u;
   const uint32_t seg_stride = kSegOut + kWindow;
-  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 16ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4 +
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 24ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4 +
                             (segs > 1 ? 8ull * segs * seg_stride : 0ull);
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
@@ -284,7 +284,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   if (int rc = ensure(cx.bufA, chunk * 4ull * nvp + 64)) return rc;
   if (int rc = ensure(cx.bufB, chunk * 4ull * nvp + 64)) return rc;
   if (greedy)
-    if (int rc = ensure(cx.bufC, chunk * 8ull * nvp + 64)) return rc;
+    if (int rc = ensure(cx.bufC, chunk * 16ull * nvp + 64)) return rc;
   if (int rc = ensure(cx.blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
   if (int rc = ensure(cx.adler, chunk * 4 + 64)) return rc;
   if (segs > 1) {

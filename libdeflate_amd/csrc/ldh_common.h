@@ -137,7 +137,7 @@ struct Batch {
   uint16_t *prevd;      // count * nvp   distance to the previous same-trigram position (0 none)
   uint32_t *bufA;       // count * nvp   sort scratch, then tokens
   uint32_t *bufB;       // count * nvp   sort scratch, then per-position best match (lazy) / rank of a position in the sorted array (greedy)
-  uint32_t *bufC;       // count * 2*nvp greedy levels only: the sorted array as {position, its first 4 bytes} pairs
+  uint32_t *bufC;       // count * 4*nvp greedy levels only: the sorted array as {position, its first 12 bytes} entries
   uint32_t *sortA, *sortB;  // k_sort_links' ping-pong arrays: bufA / bufB (sort_stride = nvp), or their own when segmented
   uint32_t sort_stride;     // elements per workgroup of k_sort_links
   uint32_t segs;            // segments per stream in k_sort_links (1: the whole stream at once)
