@@ -144,9 +144,18 @@ def main():
 
     import numpy as np
     import torch
-    dist = shard.init("nccl", torch.device("cuda", local_rank))
+    # one rank per GPU over RCCL ("nccl").  LDH_BENCH_BACKEND=gloo is the rehearsal of the N > 1 path on a box with
+    # fewer GPUs than ranks: ranks share devices (LOCAL_RANK modulo the device count) and the rendezvous runs on CPU
+    # tensors; everything else is the same code.
+    backend = os.environ.get("LDH_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and local_rank >= ndev:
+        sys.exit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    local_rank %= ndev
+    dist = shard.init(backend, torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = dev if backend == "nccl" else torch.device("cpu")  # where the rendezvous tensors live
 
     from libdeflate_amd import _native as N
     from libdeflate_amd import batch as B
@@ -177,10 +186,10 @@ def main():
     # have completed before the first *_dev call reads them
     torch.cuda.synchronize()
     # untimed warm-up, then the profiled + timed steps (barrier + sync on both sides, MAX over ranks)
-    shard.timed_steps(step, 0, args.warmup, dev_sync, dist, torch, dev)
+    shard.timed_steps(step, 0, args.warmup, dev_sync, dist, torch, rdev)
     B.profile(True)
     B.profile_reset()
-    dt = shard.timed_steps(step, args.steps, 0, dev_sync, dist, torch, dev)
+    dt = shard.timed_steps(step, args.steps, 0, dev_sync, dist, torch, rdev)
     prof = B.profile_report()
     B.profile(False)
 
@@ -220,7 +229,7 @@ def main():
         for i in range(nsamp):
             want, _ = T.o_compress(host_rows[i].tobytes(), level=args.level)
             ok = ok and cbuf[i * stride: i * stride + int(lens[i])].tobytes() == want
-    ok = shard.all_true(ok, dist, torch, dev)
+    ok = shard.all_true(ok, dist, torch, rdev)
 
     extra = {}
     if rank == 0 and world == 1 and not args.no_extra_rows and L == STREAM_LEN:
