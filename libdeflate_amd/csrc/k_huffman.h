@@ -105,20 +105,25 @@ __device__ inline void hs_push(HuffScratch &S, uint32_t e, int heap_size) {
 __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lane) {
   uint16_t *const code = (uint16_t *)S.hp;  // (zeroed and written after the heap is done with its slots)
   for (int i = lane; i < nsym; i += kWave) S.len[i] = 0;
-  // rank of every used symbol in (count, symbol) order (LD:953-955, 1002)
+  // rank of every used symbol in (count, symbol) order (LD:953-955, 1002).  The used symbols are first gathered
+  // (count << 9 | symbol: distinct keys, the order wanted is their numeric order) into the heap's slots, which are free
+  // until the heap is built, so that a symbol is compared with the used ones only: a 4 KiB block uses some 80 of the
+  // 286 literal/length symbols, and comparing every symbol with every symbol was a quarter of the kernel.
   int nleaf = 0;
   for (int base = 0; base < nsym; base += kWave) {
     const int i = base + (int)lane;
     const uint32_t ci = i < nsym ? S.cnt[i] : 0;
-    if (ci) {
-      int rank = 0;
-      for (int j = 0; j < nsym; j++) {
-        const uint32_t cj = S.cnt[j];
-        rank += (cj != 0 && (cj < ci || (cj == ci && j < i)));
-      }
-      S.leafs[rank] = (int16_t)i;
-    }
-    nleaf += __popcll(ballot64(ci != 0));
+    const unsigned long long used = ballot64(ci != 0);
+    if (ci) S.hp[nleaf + __popcll(used & ((1ull << lane) - 1ull))] = (ci << 9) | (uint32_t)i;
+    nleaf += __popcll(used);
+  }
+  __syncthreads();
+  for (int base = 0; base < nleaf; base += kWave) {
+    const int i = base + (int)lane;
+    const uint32_t ki = i < nleaf ? S.hp[i] : 0;
+    int rank = 0;
+    for (int j = 0; j < nleaf; j++) rank += S.hp[j] < ki;
+    if (i < nleaf) S.leafs[rank] = (int16_t)(ki & 511u);
   }
   __syncthreads();
   int max_nz = -1;
