@@ -653,10 +653,9 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
 // again, until nothing changes (chunk 0 is exact from the start and every repeat fixes at least
 // one more chunk; two or three repeats are the rule).  Visited positions (a 32-bit mask per lane)
 // are scanned and their tokens, rebuilt from the packed words, written out.
-constexpr int kParseThreads = 256;
+constexpr int kParseThreads = 256;        // 8192 positions per tile
+constexpr int kParseThreadsNarrow = 128;  // 4096: batches of streams up to 4 KiB (a tile of 8192 would be half empty)
 constexpr uint32_t kParseChunk = 32;
-constexpr uint32_t kParseTile = kParseThreads * kParseChunk;  // 8192 positions
-constexpr int kParseRounds = kParseTile / kParseThreads;      // positions per thread when staging
 
 // LDS slot of tile-relative position j: one pad word per chunk, so that lanes walking one
 // chunk each hit different banks
@@ -665,7 +664,11 @@ __device__ inline uint32_t parse_slot(uint32_t j) { return j + (j >> 5); }
 #ifndef LDH_PARSE_WAVES
 #define LDH_PARSE_WAVES 4  // four workgroups per CU (their LDS: 35 KB each)
 #endif
-__global__ __launch_bounds__(kParseThreads) __attribute__((amdgpu_waves_per_eu(LDH_PARSE_WAVES, LDH_PARSE_WAVES))) void k_parse_lazy(Batch B) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PARSE_WAVES, LDH_PARSE_WAVES))) void k_parse_lazy(Batch B) {
+  constexpr int kParseThreads = THREADS;
+  constexpr uint32_t kParseTile = kParseThreads * kParseChunk;
+  constexpr int kParseRounds = kParseTile / kParseThreads;  // positions per thread when staging
   __shared__ uint32_t s_tok[kParseTile + kParseTile / 32 + 2];
   __shared__ uint32_t s_wmax[kParseThreads / kWave];
   __shared__ uint32_t s_off[kParseThreads];
