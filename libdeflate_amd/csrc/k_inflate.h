@@ -358,11 +358,11 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
   bool have = false;
   const unsigned long long le_mask = (2ull << lane) - 1ull;  // lanes 0..lane
-#ifndef LDH_INFLATE_DEFER
-#define LDH_INFLATE_DEFER 0  // measured: 12.0 ms per GiB deferred against 11.2 stored at once (8192 streams)
+#ifndef LDH_INFLATE_LAZY_FENCE
+#define LDH_INFLATE_LAZY_FENCE 0  // measured: 11.3 ms per GiB against 11.0 with the fence every round; one 128 KiB string 5.05 against 4.81 ms
 #endif
-  constexpr bool kDefer = LDH_INFLATE_DEFER != 0;
-  uint32_t pend_v = 0, pend_n = 0, pend_op = 0;  // a round's output bytes kept in registers for one round (kDefer)
+  constexpr bool kLazyFence = LDH_INFLATE_LAZY_FENCE != 0;
+  uint32_t safe = 0;  // see the round's output below (stores of earlier blocks may still be in flight here)
   for (;;) {
     if (!have || rel >= 58 * 32) {
       if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
@@ -436,33 +436,24 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     const unsigned long long stops = ballot64(is_tok & (hard | err11 | full | exh));
     const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
     const bool commit = is_tok & (lane < first);
-    // ---- this round's output.  The usual case -- at most 64 bytes, every match source older than the bytes still
-    // in flight and inside the output -- is written in ONE pass, one lane per output byte: the byte's token is found
-    // from S, literals come from that token's lane, match bytes are loaded from `dist` back, all matches of
-    // the round by the same load instruction (one memory latency per round instead of one per match, and no
-    // per-match loop).  With LDH_INFLATE_DEFER the bytes are stored a round later, so that the loads' latency
-    // overlaps the next round's decode instead of ending this one.
+    // ---- this round's output.  The usual case -- at most 64 bytes, every match source older than this round's
+    // output and inside the output -- is written in ONE pass, one lane per output byte: the byte's token is found from
+    // S, literals come from that token's lane, match bytes are loaded from `dist` back, all matches of the round by
+    // the same load instruction (one memory latency per round instead of one per match, and no per-match loop).
+    // (Storing a round later, so that the loads overlap the next decode, was measured: 12.0 ms per GiB against 11.2.)
     const uint32_t n_out = first == 64 ? acc >> 8 : __builtin_amdgcn_readlane(my_off, first);
     const bool cm = commit & is_len;
-    // output below `fenced` is complete once the fence below has run (pend_n bytes from pend_op on are still in
-    // registers: loaded or decoded in the previous round, not stored yet)
-    const uint32_t fenced = pend_n ? pend_op : op;
-    // a match that reads bytes not yet stored (that includes every self-overlapping one) or the dictionary
-    const bool odd = cm & ((my_pos + mlen > fenced + dist) | (dist > my_pos));
-    const bool fast = n_out <= 64 && ballot64(odd) == 0;
-    // every store of earlier rounds must be visible to this round's match sources (this also waits for the loads
-    // of the deferred bytes)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (pend_n) {
-      if (lane < pend_n) out[pend_op + lane] = (uint8_t)pend_v;
-      pend_n = 0;
-      if (!fast) {  // the in-order path below may read them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
+    // Every store of earlier rounds must have landed before a match source among them is read.  `safe` is the output
+    // position below which every byte is known to have landed (everything stored before the last wait for a load or
+    // fence): kLazyFence pays for the fence only in a round with a match source at or beyond it.
+    if (!kLazyFence || ballot64(cm & (my_pos + mlen > safe + dist))) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      safe = op;
     }
-    if (fast) {
+    // a match that reads this round's own output (that includes every self-overlapping one) or the dictionary
+    const bool odd = cm & ((my_pos + mlen > op + dist) | (dist > my_pos));
+    if (n_out <= 64 && ballot64(odd) == 0) {
       // a token's lane leaves what its bytes are made of (the literal, or the distance) at the token's output offset;
       // a byte's lane finds its token's offset as the highest bit of S at or below its own (LDS operations of one
       // wave execute in order: no barrier between the write and the read)
@@ -470,15 +461,15 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       const unsigned long long below = S & le_mask;
       const uint32_t info = s_tk[below ? 63 - __builtin_clzll(below) : 0];
       uint32_t v = info;
-      if (lane < n_out && (info >> 31)) v = out[op + lane - (info & 0xFFFFu)];
-      if (kDefer) {
-        pend_v = v;
-        pend_n = n_out;
-        pend_op = op;
-      } else if (lane < n_out) {
-        out[op + lane] = (uint8_t)v;
-      }
+      const bool ld = (lane < n_out) & ((info >> 31) != 0);
+      if (ld) v = out[op + lane - (info & 0xFFFFu)];
+      if (kLazyFence && ballot64(ld)) safe = op;  // the store below waits for that load, and so for all earlier stores
+      if (lane < n_out) out[op + lane] = (uint8_t)v;
     } else {
+      if (kLazyFence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
       if (commit & is_lit) out[my_pos] = (uint8_t)sym;
       unsigned long long mm = ballot64(cm);
       while (mm) {  // in order, each one seeing everything stored before it
@@ -498,16 +489,16 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
           }
         }
       }
+      if (kLazyFence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        safe = op + n_out;
+      }
     }
     if (first == 64) {  // the whole window was consumed
       op += acc >> 8;
       rel += k;
       continue;
-    }
-    // ---- a stop: nothing stays deferred past this round (the paths below read or extend the output)
-    if (pend_n) {
-      if (lane < pend_n) out[pend_op + lane] = (uint8_t)pend_v;
-      pend_n = 0;
     }
     // ---- the stopping token
     const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |

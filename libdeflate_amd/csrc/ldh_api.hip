@@ -383,7 +383,10 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
           if (vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep, kMatchThreads>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles, cap);
           if (!vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep, kMatchThreads>), c * tiles, kMatchThreads, kMatchLdsBytes, B, tiles, cap);
         }
-        if (max_in_len <= kParseThreadsNarrow * kParseChunk)
+#ifndef LDH_PARSE_NARROW_MAX
+#define LDH_PARSE_NARROW_MAX (kParseThreadsNarrow * kParseChunk)
+#endif
+        if (max_in_len <= LDH_PARSE_NARROW_MAX)
           LAUNCH("k_parse_lazy", k_parse_lazy<kParseThreadsNarrow>, c * max_blocks, kParseThreadsNarrow, 0, B);
         else
           LAUNCH("k_parse_lazy", k_parse_lazy<kParseThreads>, c * max_blocks, kParseThreads, 0, B);
