@@ -381,6 +381,350 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
 #undef SRT
 }
 
+// ------------------------------------------------------------------ k_seg_links
+// The links of the lazy levels for anything longer than the narrow sort's streams, with the sort held
+// entirely in LDS.  V is cut into segments of 32768 positions.  A segment's positions (16-bit, relative
+// to the segment) are sorted by trigram where they lie: every thread holds its 32 elements in registers
+// across the workgroup's rank computation, so a pass scatters in place and nothing of the sort touches
+// memory.  Neighbours in sorted order give the links inside the segment; they are scattered by position
+// into the same LDS and leave it coalesced.  What is missing then is the link of a trigram's first
+// occurrence in a segment: chains reach back 32768 positions (LD:1365), i.e. into the segment before and
+// no further, and there only the trigram's last occurrence matters.  So every segment leaves the list of
+// its last occurrences {trigram, position}, sorted by trigram as the sort left them, and the next
+// segment's first occurrences are looked up in it (binary search, list staged through LDS a piece at a
+// time, the searches of a wave gathered into full rows of 64 first).  A workgroup takes kSegRun
+// consecutive segments of one stream so that the list goes from one iteration to the next through memory
+// it alone touches (the segment's slice of bufA / bufB, unused until k_match_lazy); a run that does not
+// begin the stream sorts the segment before it once more just for that list (any length in parallel at
+// 1.25x the work; a 128 KiB stream is one run).
+constexpr uint32_t kSegG = 32768;
+constexpr uint32_t kSegRun = 4;
+constexpr int kSegThreads = 1024;
+constexpr int kSegWaves = kSegThreads / kWave;
+constexpr int kSegItems = kSegG / kSegThreads;
+constexpr uint32_t kSegPiece = 4096;
+constexpr uint32_t kSegQueue = 128;
+constexpr uint32_t kSegLdsV = kSegG + 64;                // the segment's bytes + kVPad, 16-byte granular
+constexpr uint32_t kSegLdsBytes = kSegLdsV + 2 * kSegG;  // dynamic LDS: bytes, then elements / links
+
+// trigram at byte offset v of the staged bytes, first byte most significant (the order of the sort)
+__device__ inline uint32_t seg_key(const uint32_t *w, uint32_t v) {
+  return __builtin_amdgcn_perm(0u, lds_load4(w, v), 0x0c000102u);
+}
+
+__global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t runs) {
+  extern __shared__ uint8_t seg_lds[];
+  uint8_t *Vs = seg_lds;
+  const uint32_t *Vw = (const uint32_t *)seg_lds;
+  uint16_t *E = (uint16_t *)(seg_lds + kSegLdsV);
+  __shared__ uint16_t s_cnt[kSegWaves][256];
+  __shared__ uint16_t s_pre[kSegWaves][256];
+  __shared__ uint32_t s_base[256];
+  __shared__ uint32_t s_tot[16];
+  __shared__ uint32_t s_lcnt[kSegItems * kSegWaves];  // list entries per (row of 1024, wave), then where they go
+  __shared__ uint32_t sK[kSegPiece];  // a piece of the previous segment's list
+  __shared__ uint16_t sP[kSegPiece];
+  __shared__ uint32_t qk[kSegWaves][kSegQueue];  // look-ups waiting for a full row, per wave
+  __shared__ uint16_t qv[kSegWaves][kSegQueue];
+
+  const uint32_t s = blockIdx.x / runs, run = blockIdx.x % runs;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n = stream_len(B, s), D = B.dlen, nv_all = D + n;
+  uint8_t *Vg = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint8_t *in = B.in + B.in_off[s];
+  if (nv_all == 0) {  // only the zeros after the end
+    if (run == 0 && tid < kVPad / 4) ((uint32_t *)Vg)[tid] = 0;
+    return;
+  }
+  const uint32_t nseg = (nv_all + kSegG - 1) / kSegG;
+  const uint32_t g_first = run * kSegRun;
+  if (g_first >= nseg) return;
+  const uint32_t g_end = g_first + kSegRun < nseg ? g_first + kSegRun : nseg;
+  const bool in_aligned = (((uintptr_t)in - D) & 3) == 0;
+  for (uint32_t i = tid; i < kSegWaves * 256; i += kSegThreads) (&s_cnt[0][0])[i] = 0;
+
+  uint32_t nprev = 0;  // entries of the list the previous iteration left
+  for (uint32_t g = g_first ? g_first - 1 : 0; g < g_end; g++) {
+    const bool warm = g < g_first;        // sorted for its list only
+    const bool want_list = g + 1 < g_end; // the next iteration reads this segment's list
+    const uint32_t lo = g * kSegG, m = nv_all - lo < kSegG ? nv_all - lo : kSegG;
+    uint32_t *listK = B.bufA + (size_t)s * B.nvp + lo;             // at most m entries of 4 bytes
+    uint16_t *listP = (uint16_t *)(B.bufB + (size_t)s * B.nvp + lo);  // and of 2
+    const uint32_t *prevK = listK - (g ? kSegG : 0u);
+    const uint16_t *prevP = (const uint16_t *)(B.bufB + (size_t)s * B.nvp + lo - (g ? kSegG : 0u));
+
+    // bytes [lo, lo + m + kVPad) of V = dict ++ input ++ zeros; to memory what this segment owns (the
+    // bytes after a segment are the next one's, the zeros after the end the last one's)
+    {
+      const uint32_t total = (m + kVPad) & ~3u;
+      const uint32_t wlimit = warm ? 0u : (lo + m == nv_all ? total : m);
+      for (uint32_t w = tid * 4; w < total; w += kSegThreads * 4) {
+        uint32_t word = 0;
+        const uint32_t g0 = lo + w;
+        if (in_aligned && g0 >= D && g0 + 4 <= nv_all) {
+          word = *(const uint32_t *)(in + (g0 - D));
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t gi = g0 + k;
+            uint32_t byte = 0;
+            if (gi < nv_all) byte = gi < D ? B.dict[gi] : in[gi - D];
+            word |= byte << (8 * k);
+          }
+        }
+        if (w < wlimit) *(uint32_t *)(Vg + lo + w) = word;
+        *(uint32_t *)(Vs + w) = word;
+      }
+    }
+    __syncthreads();
+
+#ifdef LDH_SEG_STOP  // profiling builds only (-DLDH_SEG_STOP=n: skip what follows stage n; results are wrong)
+    if (LDH_SEG_STOP == 1) continue;
+#endif
+    // three passes of a stable counting sort by V[v+2], V[v+1], V[v]; wave w owns the elements
+    // [w*per*64, (w+1)*per*64), row j of them is one element per lane.  FULL: a whole segment, nothing to
+    // check per element or per row (a sixth of the instructions, and the rows' digit reads are no longer
+    // fenced in by branches).
+    auto sort_passes = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      const uint32_t per = FULL ? (uint32_t)kSegItems : (m + kSegThreads - 1) / kSegThreads;
+#pragma unroll 1
+      for (int pass = 0; pass < 3; pass++) {
+#ifdef LDH_SEG_STOP
+        if (pass + 2 > LDH_SEG_STOP) break;
+#endif
+        const uint32_t shift = 2 - pass;
+        // (opaque: what is derived from the thread index below is invariant, and hoisted out of both loops
+        // the 32 element indices alone keep 32 registers for the whole kernel)
+        uint32_t t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const uint32_t lane = t_ & 63, wave = t_ >> 6;
+        uint32_t e[kSegItems];  // position (0xFFFF: none) | its digit << 16, then | its rank among the wave's same digits << 16
+#pragma unroll
+        for (int j = 0; j < kSegItems; j++) {
+          const uint32_t idx = (wave * per + j) * 64 + lane;
+          e[j] = (FULL || ((uint32_t)j < per && idx < m)) ? (pass == 0 ? idx : (uint32_t)E[idx]) : 0xFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < kSegItems; j++)
+          if (FULL || e[j] != 0xFFFFu) e[j] |= (uint32_t)Vs[e[j] + shift] << 16;
+        // (one row after the other: two rows' ballots interleaved, to fill the wait states between a
+        // compare and the use of its mask, measured slower: 11.6 -> 12.0 ms)
+#pragma unroll
+        for (int j = 0; j < kSegItems; j++) {
+          if (FULL || (uint32_t)j < per) {
+            const bool valid = FULL || (e[j] & 0xFFFFu) != 0xFFFFu;
+            const uint32_t d = e[j] >> 16;
+            uint32_t xlo = 0, xhi = 0;  // lanes whose digit differs from mine in some bit (see k_sort_links)
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+              const uint32_t mk = (uint32_t)((int32_t)(d << (31 - bit)) >> 31);
+              const unsigned long long bal = __builtin_amdgcn_ballot_w64((int32_t)mk < 0);
+              xlo = __builtin_amdgcn_bitop3_b32(xlo, (uint32_t)bal, mk, 0xF6);
+              xhi = __builtin_amdgcn_bitop3_b32(xhi, (uint32_t)(bal >> 32), mk, 0xF6);
+            }
+            uint32_t mlo = ~xlo, mhi = ~xhi;
+            if (!FULL) {  // (lanes without an element vote with digit 0 and are masked out here)
+              const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+              mlo &= (uint32_t)vm;
+              mhi &= (uint32_t)(vm >> 32);
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
+            const uint32_t old = s_cnt[wave][d];  // same digit in this wave's earlier rows
+            e[j] = (e[j] & 0xFFFFu) | ((old + rank) << 16);  // (at most 2047)
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) s_cnt[wave][d] = (uint16_t)(old + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        __syncthreads();  // (also: every element of the pass has been read, the scatter may overwrite them)
+        uint32_t cnt = 0;
+        if (tid < 256) {  // per digit: prefix over the waves; leaves s_cnt zeroed
+#pragma unroll
+          for (int w = 0; w < kSegWaves; w++) {
+            const uint32_t t = s_cnt[w][tid];
+            s_cnt[w][tid] = 0;
+            s_pre[w][tid] = (uint16_t)cnt;
+            cnt += t;
+          }
+        }
+        scan256_exclusive(cnt, tid, s_base, s_tot);
+#pragma unroll
+        for (int j = 0; j < kSegItems; j++)
+          if (FULL || (e[j] & 0xFFFFu) != 0xFFFFu) {
+            const uint32_t d = Vs[(e[j] & 0xFFFFu) + shift];  // (read again: a register per element less)
+            E[s_base[d] + s_pre[wave][d] + (e[j] >> 16)] = (uint16_t)e[j];
+          }
+        __syncthreads();
+      }
+    };
+    if (m == kSegG)
+      sort_passes(std::true_type{});
+    else
+      sort_passes(std::false_type{});
+
+    // neighbours in sorted order: element r = j*1024 + tid; res = position | link << 15 | first << 30 | last << 31.
+    // A lane gets its neighbours' trigrams from the lanes beside it; what the ends of a row of 64 need from
+    // the rows beside it is put into LDS beforehand (the queues' space, idle until the look-ups below), so
+    // that no lane branches here.
+#ifdef LDH_SEG_STOP
+    if (LDH_SEG_STOP <= 4) continue;
+#endif
+    uint32_t *rowK0 = &qk[0][0], *rowK1 = &qk[kSegWaves / 2][0];  // trigram of a row's first / last element
+    uint16_t *rowP1 = &qv[0][0];                                  // position of its last element
+    if (tid < kSegItems * kSegWaves) {
+      const uint32_t r0 = tid * 64, r1 = r0 + 63;
+      rowK0[tid] = r0 < m ? seg_key(Vw, (uint32_t)E[r0]) : 0xFFFFFFFEu;
+      const uint32_t p1 = r1 < m ? (uint32_t)E[r1] : 0u;
+      rowK1[tid] = r1 < m ? seg_key(Vw, p1) : 0xFFFFFFFEu;
+      rowP1[tid] = (uint16_t)p1;
+    }
+    __syncthreads();
+    // (the trigram of a position is read again where it is needed below: 32 registers less)
+    uint32_t res[kSegItems];
+    uint32_t t_ = tid;  // (opaque, as in the passes)
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int j = 0; j < kSegItems; j++) {
+      const uint32_t r = j * kSegThreads + t_, row = j * kSegWaves + (t_ >> 6);
+      const bool valid = r < m;
+      const uint32_t v = valid ? (uint32_t)E[r] : 0u;
+      const uint32_t k = valid ? seg_key(Vw, v) : 0xFFFFFFFFu;
+      const uint32_t pv_in = __shfl_up(v, 1), pk_in = __shfl_up(k, 1), nk_in = __shfl_down(k, 1);
+      const uint32_t pv_row = row ? (uint32_t)rowP1[row - 1] : 0u, pk_row = row ? rowK1[row - 1] : 0xFFFFFFFEu;
+      const uint32_t nk_row = row + 1 < kSegItems * kSegWaves ? rowK0[row + 1] : 0xFFFFFFFEu;
+      const uint32_t pv = lane == 0 ? pv_row : pv_in, pk = lane == 0 ? pk_row : pk_in, nk = lane == 63 ? nk_row : nk_in;
+      const bool same = valid && pk == k;
+      const uint32_t link = same ? v - pv : 0u;
+      const uint32_t first = (valid && !same) ? 1u : 0u, last = (valid && nk != k) ? 1u : 0u;
+      res[j] = v | (link << 15) | (first << 30) | (last << 31);
+      // (opaque on purpose: the optimiser sees through the packing and keeps the four fields of all 32
+      // elements in registers of their own -- 200 spilled registers)
+      asm volatile("" : "+v"(res[j]));
+    }
+    __syncthreads();  // the elements have been read: their LDS now takes the links by position
+
+    if (!warm) {
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int j = 0; j < kSegItems; j++)
+        if ((uint32_t)j * kSegThreads + t_ < m) E[res[j] & 0x7FFFu] = (uint16_t)((res[j] >> 15) & 0x7FFFu);
+    }
+    // this segment's list, in sorted order
+    if (want_list) {
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int j = 0; j < kSegItems; j++) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64((res[j] >> 31) != 0);
+        if ((t_ & 63) == 0) s_lcnt[j * kSegWaves + (t_ >> 6)] = (uint32_t)__popcll(bal);
+      }
+    }
+    __syncthreads();
+    uint32_t ntot = 0;
+    {
+      uint32_t val = 0, inc = 0;
+      if (want_list && tid < kSegItems * kSegWaves) {
+        val = s_lcnt[tid];
+        inc = val;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(inc, off);
+          if (lane >= (uint32_t)off) inc += t;
+        }
+        if (lane == 63) s_tot[wave] = inc;
+      }
+      __syncthreads();
+      if (want_list) {
+        if (tid < kSegItems * kSegWaves) {
+          uint32_t base = 0;
+          for (uint32_t w = 0; w < wave; w++) base += s_tot[w];
+          s_lcnt[tid] = base + inc - val;
+        }
+        for (uint32_t w = 0; w < kSegItems * kSegWaves / 64; w++) ntot += s_tot[w];
+      }
+      __syncthreads();
+    }
+    if (want_list) {
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int j = 0; j < kSegItems; j++) {
+        const bool l = (res[j] >> 31) != 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(l);
+        if (l) {
+          const uint32_t slot = s_lcnt[j * kSegWaves + (t_ >> 6)] +
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+          listK[slot] = seg_key(Vw, res[j] & 0x7FFFu);
+          listP[slot] = (uint16_t)(res[j] & 0x7FFFu);
+        }
+      }
+    }
+
+    // first occurrences: look for the trigram in the list of the segment before
+#ifdef LDH_SEG_STOP
+    if (LDH_SEG_STOP <= 5) nprev = 0;
+#endif
+    if (!warm && nprev) {
+#pragma unroll 1
+      for (uint32_t p0 = 0; p0 < nprev; p0 += kSegPiece) {
+        const uint32_t pc = nprev - p0 < kSegPiece ? nprev - p0 : kSegPiece;
+        for (uint32_t i = tid; i < pc; i += kSegThreads) {
+          sK[i] = prevK[p0 + i];
+          sP[i] = prevP[p0 + i];
+        }
+        __syncthreads();
+        const uint32_t kmin = sK[0], kmax = sK[pc - 1];
+        // one search per lane: the first occurrences of a wave are gathered in its queue until 64 wait
+        auto search = [&](uint32_t at, bool act) {
+          const uint32_t k = act ? qk[wave][at] : 0u, v = act ? (uint32_t)qv[wave][at] : 0u;
+          uint32_t b = 0, len = pc;
+          while (len > 1) {  // (uniform: pc is)
+            const uint32_t half = len >> 1;
+            if (sK[b + half] <= k) b += half;
+            len -= half;
+          }
+          if (act && sK[b] == k) {
+            const uint32_t u = sP[b];
+            if (u >= v) E[v] = (uint16_t)(kSegG + v - u);  // distance <= 32768
+          }
+        };
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kSegItems; j++) {
+          const bool f0 = ((res[j] >> 30) & 1u) != 0;
+          if (!__builtin_amdgcn_ballot_w64(f0)) continue;
+          const uint32_t kj = f0 ? seg_key(Vw, res[j] & 0x7FFFu) : 0u;
+          const bool f = f0 && kj >= kmin && kj <= kmax;
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+          if (bal) {
+            if (f) {
+              const uint32_t slot = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+              qk[wave][slot] = kj;
+              qv[wave][slot] = (uint16_t)(res[j] & 0x7FFFu);
+            }
+            cnt += (uint32_t)__popcll(bal);
+            __builtin_amdgcn_wave_barrier();
+            if (cnt >= 64) {
+              search(cnt - 64 + lane, true);
+              cnt -= 64;
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+        if (cnt) search(lane, lane < cnt);
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+    if (!warm) {  // links out, in order (rows of prevd and lo are 4-byte aligned)
+      const uint32_t *src32 = (const uint32_t *)E;
+      uint32_t *dst32 = (uint32_t *)(B.prevd + (size_t)s * B.nvp + lo);
+      for (uint32_t i = tid; i < (m + 1) / 2; i += kSegThreads) dst32[i] = src32[i];
+    }
+    __syncthreads();
+    nprev = want_list ? ntot : 0u;
+  }
+}
+
 // ------------------------------------------------------------------ k_match_lazy
 #ifndef LDH_MATCH_TILE
 #define LDH_MATCH_TILE 20480

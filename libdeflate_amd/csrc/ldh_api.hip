@@ -272,7 +272,10 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   // k_sort_links keeps what it sorts in LDS; a longer V (a dictionary in front of 128 KiB, or one
   // long stream) is sorted in segments of at most 131072 positions with ping-pong arrays of their own
   const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
-  const uint32_t segs = (!sort_in_lds && need_lz && !greedy) ? (uint32_t)((vd + max_in_len + kSegOut - 1) / kSegOut) : 1u;
+  // lazy levels, streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS)
+  const bool seg_links = need_lz && !greedy && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds && !getenv("LDH_OLD_SORT");
+  const uint32_t seg_runs = (uint32_t)((((size_t)vd + max_in_len + kSegG - 1) / kSegG + kSegRun - 1) / kSegRun);
+  const uint32_t segs = (!seg_links && !sort_in_lds && need_lz && !greedy) ? (uint32_t)((vd + max_in_len + kSegOut - 1) / kSegOut) : 1u;
   const uint32_t seg_stride = kSegOut + kWindow;
   const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 24ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4 +
                             (segs > 1 ? 8ull * segs * seg_stride : 0ull);
@@ -297,6 +300,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   if (!cx.attr_done) {
     HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true, kSortThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(kSortLdsMaxV)));
+    HIPCHK(hipFuncSetAttribute((const void *)k_seg_links, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSegLdsBytes));
     for (const void *f : {(const void *)k_match_lazy<false, 1, kMatchThreads>, (const void *)k_match_lazy<true, 1, kMatchThreads>,
                           (const void *)k_match_lazy<false, kRefillMinDeep, kMatchThreads>,
                           (const void *)k_match_lazy<true, kRefillMinDeep, kMatchThreads>})
@@ -356,7 +360,9 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, cx.stream));
     }
     // V (and, for the match search, the trigram chains)
-    if (B.sort_lds && B.sort_lds <= kSortNarrowMaxLds)
+    if (seg_links)
+      LAUNCH("k_seg_links", k_seg_links, c * seg_runs, kSegThreads, kSegLdsBytes, B, seg_runs);
+    else if (B.sort_lds && B.sort_lds <= kSortNarrowMaxLds)
       LAUNCH("k_sort_links", (k_sort_links<true, kSortThreadsNarrow>), c, kSortThreadsNarrow, B.sort_lds, B);
     else if (B.sort_lds)
       LAUNCH("k_sort_links", (k_sort_links<true, kSortThreads>), c * segs, kSortThreads, B.sort_lds, B);
