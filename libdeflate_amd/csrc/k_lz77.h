@@ -458,19 +458,39 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
     {
       const uint32_t total = (m + kVPad) & ~3u;
       const uint32_t wlimit = warm ? 0u : (lo + m == nv_all ? total : m);
-      for (uint32_t w = tid * 4; w < total; w += kSegThreads * 4) {
+      // whole dwords of the input (where it is 4-byte aligned relative to V, the usual case): all of a
+      // thread's loads in flight at once -- one workgroup per CU has nothing else to hide them behind
+      // (a load, a store and the next load in turn took 0.9 of the kernel's 11.6 ms)
+      const uint32_t nfull = (in_aligned && lo >= D) ? ((nv_all - lo) / 4 < total / 4 ? (nv_all - lo) / 4 : total / 4) : 0u;
+      uint32_t ts = tid;  // (opaque: or the eighteen 64-bit addresses below are kept for the whole kernel)
+      asm volatile("" : "+v"(ts));
+      {
+        const uint32_t *src = (const uint32_t *)(in + (lo >= D ? lo - D : 0u));
+        constexpr int kW = kSegG / 4 / kSegThreads;  // 8
+        uint32_t wd[kW + 1];
+#pragma unroll
+        for (int i = 0; i <= kW; i++) {
+          const uint32_t idx = i * kSegThreads + ts;
+          wd[i] = idx < nfull ? src[idx] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i <= kW; i++) {
+          const uint32_t idx = i * kSegThreads + ts;
+          if (idx < nfull) {
+            if (idx * 4 < wlimit) *(uint32_t *)(Vg + lo + idx * 4) = wd[i];
+            *(uint32_t *)(Vs + idx * 4) = wd[i];
+          }
+        }
+      }
+      for (uint32_t w = (nfull + ts) * 4; w < total; w += kSegThreads * 4) {  // the rest byte by byte
         uint32_t word = 0;
         const uint32_t g0 = lo + w;
-        if (in_aligned && g0 >= D && g0 + 4 <= nv_all) {
-          word = *(const uint32_t *)(in + (g0 - D));
-        } else {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const uint32_t gi = g0 + k;
-            uint32_t byte = 0;
-            if (gi < nv_all) byte = gi < D ? B.dict[gi] : in[gi - D];
-            word |= byte << (8 * k);
-          }
+        for (int k = 0; k < 4; k++) {
+          const uint32_t gi = g0 + k;
+          uint32_t byte = 0;
+          if (gi < nv_all) byte = gi < D ? B.dict[gi] : in[gi - D];
+          word |= byte << (8 * k);
         }
         if (w < wlimit) *(uint32_t *)(Vg + lo + w) = word;
         *(uint32_t *)(Vs + w) = word;
@@ -552,7 +572,9 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
 #pragma unroll
         for (int j = 0; j < kSegItems; j++)
           if (FULL || (e[j] & 0xFFFFu) != 0xFFFFu) {
-            const uint32_t d = Vs[(e[j] & 0xFFFFu) + shift];  // (read again: a register per element less)
+            // (the digit is read again: kept in registers, four to one, the packing and unpacking cost
+            // more vector instructions than the LDS read saves -- 11.1 -> 11.6 ms)
+            const uint32_t d = Vs[(e[j] & 0xFFFFu) + shift];
             E[s_base[d] + s_pre[wave][d] + (e[j] >> 16)] = (uint16_t)e[j];
           }
         __syncthreads();
@@ -674,8 +696,8 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
         __syncthreads();
         const uint32_t kmin = sK[0], kmax = sK[pc - 1];
         // one search per lane: the first occurrences of a wave are gathered in its queue until 64 wait
-        auto search = [&](uint32_t at, bool act) {
-          const uint32_t k = act ? qk[wave][at] : 0u, v = act ? (uint32_t)qv[wave][at] : 0u;
+        auto search = [&](uint32_t wq, uint32_t at, bool act) {
+          const uint32_t k = act ? qk[wq][at] : 0u, v = act ? (uint32_t)qv[wq][at] : 0u;
           uint32_t b = 0, len = pc;
           while (len > 1) {  // (uniform: pc is)
             const uint32_t half = len >> 1;
@@ -690,6 +712,11 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
         uint32_t cnt = 0;
 #pragma unroll
         for (int j = 0; j < kSegItems; j++) {
+          // (thread index opaque per element: the queue addresses derived from it are two instructions
+          // to make; hoisted, they were spilled and reloaded from scratch memory 160 times per piece)
+          uint32_t tq = t_;
+          asm volatile("" : "+v"(tq));
+          const uint32_t lq = tq & 63, wq = tq >> 6;
           const bool f0 = ((res[j] >> 30) & 1u) != 0;
           if (!__builtin_amdgcn_ballot_w64(f0)) continue;
           const uint32_t kj = f0 ? seg_key(Vw, res[j] & 0x7FFFu) : 0u;
@@ -698,19 +725,19 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
           if (bal) {
             if (f) {
               const uint32_t slot = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-              qk[wave][slot] = kj;
-              qv[wave][slot] = (uint16_t)(res[j] & 0x7FFFu);
+              qk[wq][slot] = kj;
+              qv[wq][slot] = (uint16_t)(res[j] & 0x7FFFu);
             }
             cnt += (uint32_t)__popcll(bal);
             __builtin_amdgcn_wave_barrier();
             if (cnt >= 64) {
-              search(cnt - 64 + lane, true);
+              search(wq, cnt - 64 + lq, true);
               cnt -= 64;
               __builtin_amdgcn_wave_barrier();
             }
           }
         }
-        if (cnt) search(lane, lane < cnt);
+        if (cnt) search(wave, lane, lane < cnt);
         __syncthreads();
       }
     }
@@ -718,7 +745,8 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
     if (!warm) {  // links out, in order (rows of prevd and lo are 4-byte aligned)
       const uint32_t *src32 = (const uint32_t *)E;
       uint32_t *dst32 = (uint32_t *)(B.prevd + (size_t)s * B.nvp + lo);
-      for (uint32_t i = tid; i < (m + 1) / 2; i += kSegThreads) dst32[i] = src32[i];
+      asm volatile("" : "+v"(t_));
+      for (uint32_t i = t_; i < (m + 1) / 2; i += kSegThreads) dst32[i] = src32[i];
     }
     __syncthreads();
     nprev = want_list ? ntot : 0u;
