@@ -419,7 +419,6 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
   uint16_t *E = (uint16_t *)(seg_lds + kSegLdsV);
   __shared__ uint16_t s_cnt[kSegWaves][256];
   __shared__ uint16_t s_pre[kSegWaves][256];
-  __shared__ uint32_t s_base[256];
   __shared__ uint32_t s_tot[16];
   __shared__ uint32_t s_lcnt[kSegItems * kSegWaves];  // list entries per (row of 1024, wave), then where they go
   __shared__ uint32_t sK[kSegPiece];  // a piece of the previous segment's list
@@ -558,24 +557,44 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
           }
         }
         __syncthreads();  // (also: every element of the pass has been read, the scatter may overwrite them)
-        uint32_t cnt = 0;
-        if (tid < 256) {  // per digit: prefix over the waves; leaves s_cnt zeroed
+        // per digit: where each wave's elements go = elements with smaller digits + those of earlier
+        // waves (one table for the scatter to read, not a base and a prefix); leaves s_cnt zeroed
+        {
+          uint32_t tot = 0;
+          if (tid < 256) {
 #pragma unroll
-          for (int w = 0; w < kSegWaves; w++) {
-            const uint32_t t = s_cnt[w][tid];
-            s_cnt[w][tid] = 0;
-            s_pre[w][tid] = (uint16_t)cnt;
-            cnt += t;
+            for (int w = 0; w < kSegWaves; w++) tot += s_cnt[w][tid];
           }
+          uint32_t inc = tot;
+          if (tid < 256) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const uint32_t t = __shfl_up(inc, off);
+              if (lane >= (uint32_t)off) inc += t;
+            }
+            if (lane == 63) s_tot[wave] = inc;
+          }
+          __syncthreads();
+          if (tid < 256) {
+            uint32_t at = inc - tot;
+            for (uint32_t w = 0; w < wave; w++) at += s_tot[w];
+#pragma unroll
+            for (int w = 0; w < kSegWaves; w++) {  // (the counts are read a second time: 16 registers less)
+              const uint32_t c = s_cnt[w][tid];
+              s_cnt[w][tid] = 0;
+              s_pre[w][tid] = (uint16_t)at;  // (at most 32767)
+              at += c;
+            }
+          }
+          __syncthreads();
         }
-        scan256_exclusive(cnt, tid, s_base, s_tot);
 #pragma unroll
         for (int j = 0; j < kSegItems; j++)
           if (FULL || (e[j] & 0xFFFFu) != 0xFFFFu) {
             // (the digit is read again: kept in registers, four to one, the packing and unpacking cost
             // more vector instructions than the LDS read saves -- 11.1 -> 11.6 ms)
             const uint32_t d = Vs[(e[j] & 0xFFFFu) + shift];
-            E[s_base[d] + s_pre[wave][d] + (e[j] >> 16)] = (uint16_t)e[j];
+            E[(uint32_t)s_pre[wave][d] + (e[j] >> 16)] = (uint16_t)e[j];
           }
         __syncthreads();
       }
