@@ -88,11 +88,7 @@ __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *o
 // per-element key fetches of passes 1-2 and the trigram compares of the link pass are LDS
 // byte reads instead of fully divergent global loads (which bound the first version).
 constexpr uint32_t kSortLdsMaxV = 131072 + 64;
-// A virtual buffer too long for that (a 128 KiB stream behind a 32 KiB dictionary; SURVEY 8.f N4:
-// one long stream) is sorted in segments, one workgroup each: chains never reach back more than
-// 32768 positions (LD:1365), so the links of positions [g*kSegOut, (g+1)*kSegOut) need only the
-// positions from g*kSegOut - 32768 on.  A segment sorts at most 131072 positions.
-constexpr uint32_t kSegOut = 131072 - kWindow;
+// (lazy levels with streams beyond the narrow version's go to k_seg_links below, whatever their length)
 
 // THREADS: 1024, or 256 for batches of short streams (a 4 KiB stream is half a tile of the wide
 // version, and four times as many workgroups fit a CU)
@@ -110,21 +106,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
   __shared__ uint16_t s_pre[kSortWaves][256];
   __shared__ uint32_t s_tot[4];
 
-  const uint32_t s = blockIdx.x / B.segs, seg = blockIdx.x % B.segs;
+  const uint32_t s = blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t n = stream_len(B, s), D = B.dlen, nv_all = D + n;
-  // this workgroup sorts V positions [lo, hi) and produces the links of [out0, hi); all element
-  // indices below are relative to lo.  One segment: lo = out0 = 0, hi = nv_all.
-  const uint32_t out0 = B.segs > 1 ? seg * kSegOut : 0u;
-  if (seg > 0 && out0 >= nv_all) return;
-  const uint32_t hi = (B.segs > 1 && out0 + kSegOut < nv_all) ? out0 + kSegOut : nv_all;
-  const uint32_t lo = out0 > kWindow ? out0 - kWindow : 0u;
-  const uint32_t nv = hi - lo, keep0 = out0 - lo;
-  uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad) + lo;
+  const uint32_t n = stream_len(B, s), D = B.dlen, nv_all = D + n, nv = nv_all;
+  uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
   const uint8_t *in = B.in + B.in_off[s];
-  uint32_t *bufA = B.sortA + (size_t)blockIdx.x * B.sort_stride;
-  uint32_t *bufB = B.sortB + (size_t)blockIdx.x * B.sort_stride;
-  uint16_t *prevd = B.prevd + (size_t)s * B.nvp + lo;
+  uint32_t *bufA = B.bufA + (size_t)s * B.nvp;
+  uint32_t *bufB = B.bufB + (size_t)s * B.nvp;
+  uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
   // where the sorted array ends up; greedy levels also get its inverse (rank of a position)
   // (greedy levels: entries of the final array carry the first twelve bytes of their position too)
   uint4 *srt2 = B.want_rank ? (uint4 *)B.bufC + (size_t)s * B.nvp : nullptr;
@@ -136,15 +125,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
   for (uint32_t i = tid; i < kSortWaves * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
 
-  // V = dict ++ input ++ zeros, written as dwords (V and lo are 4-byte aligned).  The kVPad bytes
-  // after the segment are the next segment's first bytes, or the zeros after the stream's end.
-  // Global V is written from out0 on (what lies before is another segment's to write).
-  const uint32_t total = (nv + kVPad) & ~3u;  // lo + nv + kVPad <= nvp + kVPad
+  // V = dict ++ input ++ zeros, written as dwords (V is 4-byte aligned)
+  const uint32_t total = (nv + kVPad) & ~3u;  // nv + kVPad <= nvp + kVPad
   // (whole dwords of the input where it is 4-byte aligned relative to V: the usual case)
   const bool in_aligned = (((uintptr_t)in - D) & 3) == 0;
   for (uint32_t w = tid * 4; w < total; w += kSortThreads * 4) {
     uint32_t word = 0;
-    const uint32_t g0 = lo + w;
+    const uint32_t g0 = w;
     if (in_aligned && g0 >= D && g0 + 4 <= nv_all) {
       word = *(const uint32_t *)(in + (g0 - D));
     } else {
@@ -159,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (w + k < nv) atomicAdd(&s_hist[(word >> (8 * k)) & 255u], 1u);
-    if (w >= keep0) *(uint32_t *)(V + w) = word;
+    *(uint32_t *)(V + w) = word;
     if (V_LDS) *(uint32_t *)(ldsV + w) = word;
   }
   __syncthreads();
@@ -278,7 +265,6 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
 #endif
   if (B.want_rank) {
     // greedy levels walk the sorted array itself (k_lz_greedy): no links, only the inverse permutation
-    // (never segmented: the host keeps segs = 1 for these levels)
     if (V_LDS) {
       // like the links below: scattering 4-byte ranks by position straight to memory took longer than
       // the three sort passes together; V's LDS (free now) takes the ranks of a quarter of the positions
@@ -341,7 +327,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
     __syncthreads();
     uint16_t *l16 = (uint16_t *)ldsV;
     const uint32_t H = (B.sort_lds / 2) & ~1u;  // positions whose links fit V's LDS (>= 24, even)
-    for (uint32_t h0 = keep0; h0 < nv; h0 += H) {  // (positions before out0 are only predecessors here)
+    for (uint32_t h0 = 0; h0 < nv; h0 += H) {
       for (uint32_t r0 = tid; r0 < nv; r0 += kSortThreads * kLinkItems) {
         uint32_t v[kLinkItems], l[kLinkItems];
 #pragma unroll
@@ -355,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
           if (v[j] != 0xFFFFFFFFu && v[j] - h0 < H) l16[v[j] - h0] = (uint16_t)l[j];
       }
       __syncthreads();
-      const uint32_t cnt = nv - h0 < H ? nv - h0 : H;  // prevd rows, lo, keep0 and H are even: 4-byte aligned
+      const uint32_t cnt = nv - h0 < H ? nv - h0 : H;  // prevd rows and H are even: 4-byte aligned
       const uint32_t *src32 = (const uint32_t *)l16;
       uint32_t *dst32 = (uint32_t *)(prevd + h0);
       for (uint32_t i = tid; i < (cnt + 1) / 2; i += kSortThreads) dst32[i] = src32[i];

@@ -84,7 +84,7 @@ struct Ctx {
   std::mutex mu;
   hipStream_t stream = nullptr, s_in = nullptr, s_out = nullptr;
   // workspace (grow-only)
-  DevBuf vbuf, prevd, bufA, bufB, bufC, sortA, sortB, blocks, adler, misc32a, misc32b;
+  DevBuf vbuf, prevd, bufA, bufB, bufC, blocks, adler, misc32a, misc32b;
   // staging for the host-pointer entry points
   DevBuf h_in, h_off, h_out, h_len, h_aux8, h_aux32a, h_aux32b, codec_tmp;
   Slot slot[3];
@@ -269,16 +269,12 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   const uint32_t max_blocks = num_blocks((uint32_t)max_in_len);
 
   const bool greedy = need_lz && !level_cfg(level).lazy;  // levels 1-3
-  // k_sort_links keeps what it sorts in LDS; a longer V (a dictionary in front of 128 KiB, or one
-  // long stream) is sorted in segments of at most 131072 positions with ping-pong arrays of their own
-  const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
-  // lazy levels, streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS)
-  const bool seg_links = need_lz && !greedy && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds && !getenv("LDH_OLD_SORT");
+  // lazy levels, streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS, any length)
+  const bool seg_links = need_lz && !greedy && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds;
   const uint32_t seg_runs = (uint32_t)((((size_t)vd + max_in_len + kSegG - 1) / kSegG + kSegRun - 1) / kSegRun);
-  const uint32_t segs = (!seg_links && !sort_in_lds && need_lz && !greedy) ? (uint32_t)((vd + max_in_len + kSegOut - 1) / kSegOut) : 1u;
-  const uint32_t seg_stride = kSegOut + kWindow;
-  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 24ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4 +
-                            (segs > 1 ? 8ull * segs * seg_stride : 0ull);
+  // the rest (greedy levels, short streams, V alone for level 0 / huffman_only): k_sort_links, in LDS when V fits there
+  const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 24ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
 
@@ -290,10 +286,6 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     if (int rc = ensure(cx.bufC, chunk * 16ull * nvp + 64)) return rc;
   if (int rc = ensure(cx.blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
   if (int rc = ensure(cx.adler, chunk * 4 + 64)) return rc;
-  if (segs > 1) {
-    if (int rc = ensure(cx.sortA, chunk * 4ull * segs * seg_stride + 64)) return rc;
-    if (int rc = ensure(cx.sortB, chunk * 4ull * segs * seg_stride + 64)) return rc;
-  }
 
   const uint8_t *d_dict = nullptr;
   if (dict && !(d_dict = dict_on(cx, dict))) return fail(LDH_E_NOMEM, "dictionary upload to device %d failed", cx.device);
@@ -329,11 +321,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     B.bufB = (uint32_t *)cx.bufB.p;
     B.bufC = greedy ? (uint32_t *)cx.bufC.p : nullptr;
     B.want_rank = greedy ? 1u : 0u;
-    B.segs = segs;
-    B.sortA = segs > 1 ? (uint32_t *)cx.sortA.p : B.bufA;
-    B.sortB = segs > 1 ? (uint32_t *)cx.sortB.p : B.bufB;
-    B.sort_stride = segs > 1 ? seg_stride : nvp;
-    B.sort_lds = segs > 1 ? ((seg_stride + kVPad + 15) & ~15u) : (sort_in_lds ? ((nvp + kVPad + 15) & ~15u) : 0u);
+    B.sort_lds = sort_in_lds ? ((nvp + kVPad + 15) & ~15u) : 0u;
     B.need_lz = need_lz ? 1u : 0u;
     B.blocks = (BlockInfo *)cx.blocks.p;
     B.adler = (uint32_t *)cx.adler.p;
@@ -352,10 +340,6 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
       HIPCHK(hipMemsetAsync(cx.bufA.p, 0xA5, cx.bufA.cap, cx.stream));
       HIPCHK(hipMemsetAsync(cx.bufB.p, 0xA5, cx.bufB.cap, cx.stream));
       if (greedy) HIPCHK(hipMemsetAsync(cx.bufC.p, 0xA5, cx.bufC.cap, cx.stream));
-      if (segs > 1) {
-        HIPCHK(hipMemsetAsync(cx.sortA.p, 0xA5, cx.sortA.cap, cx.stream));
-        HIPCHK(hipMemsetAsync(cx.sortB.p, 0xA5, cx.sortB.cap, cx.stream));
-      }
       HIPCHK(hipMemsetAsync(cx.blocks.p, 0xA5, cx.blocks.cap, cx.stream));
       HIPCHK(hipMemsetAsync(B.out, 0xA5, (size_t)c * out_stride, cx.stream));
     }
@@ -365,7 +349,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     else if (B.sort_lds && B.sort_lds <= kSortNarrowMaxLds)
       LAUNCH("k_sort_links", (k_sort_links<true, kSortThreadsNarrow>), c, kSortThreadsNarrow, B.sort_lds, B);
     else if (B.sort_lds)
-      LAUNCH("k_sort_links", (k_sort_links<true, kSortThreads>), c * segs, kSortThreads, B.sort_lds, B);
+      LAUNCH("k_sort_links", (k_sort_links<true, kSortThreads>), c, kSortThreads, B.sort_lds, B);
     else
       LAUNCH("k_sort_links", (k_sort_links<false, kSortThreads>), c, kSortThreads, 0, B);
     if (level != 0) {
@@ -621,7 +605,7 @@ void ctx_destroy(Ctx *c) {
   hipDeviceSynchronize();
   Ctx &cx = *c;
   pipeline_free(cx);
-  for (DevBuf *b : {&cx.vbuf, &cx.prevd, &cx.bufA, &cx.bufB, &cx.bufC, &cx.sortA, &cx.sortB, &cx.blocks, &cx.adler, &cx.misc32a, &cx.misc32b, &cx.h_in,
+  for (DevBuf *b : {&cx.vbuf, &cx.prevd, &cx.bufA, &cx.bufB, &cx.bufC, &cx.blocks, &cx.adler, &cx.misc32a, &cx.misc32b, &cx.h_in,
                     &cx.h_off, &cx.h_out, &cx.h_len, &cx.h_aux8, &cx.h_aux32a, &cx.h_aux32b, &cx.codec_tmp}) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;

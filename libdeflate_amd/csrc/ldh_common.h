@@ -138,9 +138,6 @@ struct Batch {
   uint32_t *bufA;       // count * nvp   sort scratch, then tokens
   uint32_t *bufB;       // count * nvp   sort scratch, then per-position best match (lazy) / rank of a position in the sorted array (greedy)
   uint32_t *bufC;       // count * 4*nvp greedy levels only: the sorted array as {position, its first 12 bytes} entries
-  uint32_t *sortA, *sortB;  // k_sort_links' ping-pong arrays: bufA / bufB (sort_stride = nvp), or their own when segmented
-  uint32_t sort_stride;     // elements per workgroup of k_sort_links
-  uint32_t segs;            // segments per stream in k_sort_links (1: the whole stream at once)
   uint32_t sort_lds;        // bytes of dynamic LDS k_sort_links<true> is launched with (0 for <false>)
   uint32_t need_lz;     // 0: level 0 / huffman_only, k_sort_links only materialises V
   uint32_t want_rank;   // k_sort_links leaves sorted array in bufC and its inverse in bufB (greedy levels)

@@ -196,24 +196,40 @@ def test_large_streams(LD, B):
 
 
 def test_segmented_sort(LD, B):
-    # lazy levels sort a virtual buffer that does not fit LDS in segments of 131072 positions (98304 of them new):
-    # BASELINE configs[3] shape (128 KiB streams behind the 32 KiB dictionary), one long stream next to
-    # short ones (segments past a stream's end), and lengths around the segment edges
+    # lazy levels build the chains of anything longer than 16 KiB in segments of 32768 positions sorted inside LDS
+    # (k_seg_links); a first occurrence's link comes from the previous segment's last-occurrence list, runs of four
+    # segments share a workgroup and later runs sort the segment before them once more.  BASELINE configs[3] shape
+    # (128 KiB streams behind the 32 KiB dictionary: five segments, two runs), one long stream next to
+    # short ones (runs past a stream's end), and lengths around the segment and run edges
     from libdeflate_amd import synth
     dct = golden("dictionary32768.txt")
     d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
     text = [r.tobytes() for r in synth.text_streams(3, 131072)]
-    text += [dct[5000:9000] + text[0][:70000], text[1][:98304 - 32768 + 1], b""]
+    text += [dct[5000:9000] + text[0][:70000], text[1][:98304 - 32768 + 1], text[2][:32768], text[2][:32769], b""]
     for level in (5, 8):
         for s, g in zip(text, B.compress_batch(text, fmt=1, level=level, dictionary=d)):
             assert g == o_compress(s, zlib=True, level=level, dict=dct), (level, len(s))
     long_one = b"".join(r.tobytes() for r in synth.text_streams(20, 131072))[:2500001]
     edge = [long_one, long_one[:98304], long_one[:98305], long_one[:131073], long_one[:196608], long_one[:196609], b"q"]
+    edge += [long_one[7:7 + n] for n in (16385, 32767, 32768, 32769, 65535, 65536, 65537, 131071, 131072, 163841, 262144, 262145)]
     got = B.compress_batch(edge, level=5)
     for s, g in zip(edge, got):
         assert g == o_compress(s, level=5), len(s)
     back = B.decompress_batch([c for c, _ in got], max_out=len(long_one))
     assert [x for x, _ in back] == edge
+    # a short dictionary in front: segment edges no longer fall on multiples of 32768 of the input, and the input is
+    # not dword-aligned relative to V (the byte-wise staging path)
+    d5 = LD.CreateDictionary(dct[-5:], 5, o_adler32(dct[-5:]))
+    some = [long_one[:n] for n in (32763, 32764, 65531, 131067, 140000)]
+    for s, g in zip(some, B.compress_batch(some, level=6, dictionary=d5)):
+        assert g == o_compress(s, level=6, dict=dct[-5:]), len(s)
+    # data whose trigrams are all different inside a segment and recur one segment later (every position is a
+    # first occurrence: the look-up lists are full, several pieces), and data with one trigram only
+    rng = np.random.default_rng(7)
+    blk = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    odd = [blk * 3 + blk[:100], blk[:20000] + blk[:20000] + blk, b"\0" * 100000, (blk[:3] * 40000)[:100003]]
+    for s, g in zip(odd, B.compress_batch(odd, level=4)):
+        assert g == o_compress(s, level=4), len(s)
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 15, 16, 17, 47, 48, 63, 64, 65, 80, 127, 128, 129])
