@@ -378,11 +378,12 @@ __global__ __launch_bounds__(THREADS) void k_sort_links(Batch B) {
 // no further, and there only the trigram's last occurrence matters.  So every segment leaves the list of
 // its last occurrences {trigram, position}, sorted by trigram as the sort left them, and the next
 // segment's first occurrences are looked up in it (binary search, list staged through LDS a piece at a
-// time, the searches of a wave gathered into full rows of 64 first).  A workgroup takes kSegRun
+// time, the searches of a wave gathered into full rows of 64 first).  A workgroup takes a run of
 // consecutive segments of one stream so that the list goes from one iteration to the next through memory
 // it alone touches (the segment's slice of bufA / bufB, unused until k_match_lazy); a run that does not
-// begin the stream sorts the segment before it once more just for that list (any length in parallel at
-// 1.25x the work; a 128 KiB stream is one run).
+// begin the stream sorts the segment before it once more just for that list.  The host picks the run
+// length: whole streams when the batch has workgroups enough without cutting them (no segment sorted
+// twice), else kSegRun segments (any length in parallel at 1.25x the work).
 constexpr uint32_t kSegG = 32768;
 constexpr uint32_t kSegRun = 4;
 constexpr int kSegThreads = 1024;
@@ -398,7 +399,7 @@ __device__ inline uint32_t seg_key(const uint32_t *w, uint32_t v) {
   return __builtin_amdgcn_perm(0u, lds_load4(w, v), 0x0c000102u);
 }
 
-__global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t runs) {
+__global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t runs, uint32_t run_len) {
   extern __shared__ uint8_t seg_lds[];
   uint8_t *Vs = seg_lds;
   const uint32_t *Vw = (const uint32_t *)seg_lds;
@@ -422,9 +423,9 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
     return;
   }
   const uint32_t nseg = (nv_all + kSegG - 1) / kSegG;
-  const uint32_t g_first = run * kSegRun;
+  const uint32_t g_first = run * run_len;
   if (g_first >= nseg) return;
-  const uint32_t g_end = g_first + kSegRun < nseg ? g_first + kSegRun : nseg;
+  const uint32_t g_end = g_first + run_len < nseg ? g_first + run_len : nseg;
   const bool in_aligned = (((uintptr_t)in - D) & 3) == 0;
   for (uint32_t i = tid; i < kSegWaves * 256; i += kSegThreads) (&s_cnt[0][0])[i] = 0;
 
@@ -443,33 +444,44 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
     {
       const uint32_t total = (m + kVPad) & ~3u;
       const uint32_t wlimit = warm ? 0u : (lo + m == nv_all ? total : m);
-      // whole dwords of the input (where it is 4-byte aligned relative to V, the usual case): all of a
-      // thread's loads in flight at once -- one workgroup per CU has nothing else to hide them behind
-      // (a load, a store and the next load in turn took 0.9 of the kernel's 11.6 ms)
-      const uint32_t nfull = (in_aligned && lo >= D) ? ((nv_all - lo) / 4 < total / 4 ? (nv_all - lo) / 4 : total / 4) : 0u;
-      uint32_t ts = tid;  // (opaque: or the eighteen 64-bit addresses below are kept for the whole kernel)
+      // whole dwords of the dictionary and of the input (where it is 4-byte aligned relative to V, the
+      // usual case): all of a thread's loads in flight at once -- one workgroup per CU has nothing else
+      // to hide them behind (a load, a store and the next load in turn took 0.9 of the kernel's 11.6 ms)
+      const uint32_t nw = total / 4;
+      const bool dict_al = (((uintptr_t)B.dict) & 3) == 0;
+      // 1: a dword of the dictionary, 2: of the input, 0: bytes (an edge, or nothing aligned)
+      auto kind = [&](uint32_t idx) -> uint32_t {
+        const uint32_t g0 = lo + idx * 4;
+        if (dict_al && g0 + 4 <= D) return 1u;
+        if (in_aligned && g0 >= D && g0 + 4 <= nv_all) return 2u;
+        return 0u;
+      };
+      uint32_t ts = tid;  // (opaque: or the addresses below are kept, spilled, for the whole kernel)
       asm volatile("" : "+v"(ts));
       {
-        const uint32_t *src = (const uint32_t *)(in + (lo >= D ? lo - D : 0u));
         constexpr int kW = kSegG / 4 / kSegThreads;  // 8
         uint32_t wd[kW + 1];
 #pragma unroll
         for (int i = 0; i <= kW; i++) {
-          const uint32_t idx = i * kSegThreads + ts;
-          wd[i] = idx < nfull ? src[idx] : 0u;
+          const uint32_t idx = i * kSegThreads + ts, g0 = lo + idx * 4;
+          const uint32_t kd = idx < nw ? kind(idx) : 0u;
+          wd[i] = 0;
+          if (kd == 1) wd[i] = *(const uint32_t *)(B.dict + g0);
+          if (kd == 2) wd[i] = *(const uint32_t *)(in + (g0 - D));
         }
 #pragma unroll
         for (int i = 0; i <= kW; i++) {
           const uint32_t idx = i * kSegThreads + ts;
-          if (idx < nfull) {
+          if (idx < nw && kind(idx)) {
             if (idx * 4 < wlimit) *(uint32_t *)(Vg + lo + idx * 4) = wd[i];
             *(uint32_t *)(Vs + idx * 4) = wd[i];
           }
         }
       }
-      for (uint32_t w = (nfull + ts) * 4; w < total; w += kSegThreads * 4) {  // the rest byte by byte
+      for (uint32_t idx = ts; idx < nw; idx += kSegThreads) {  // the rest byte by byte
+        if (kind(idx)) continue;
         uint32_t word = 0;
-        const uint32_t g0 = lo + w;
+        const uint32_t w = idx * 4, g0 = lo + w;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const uint32_t gi = g0 + k;

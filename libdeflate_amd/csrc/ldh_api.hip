@@ -271,7 +271,11 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   const bool greedy = need_lz && !level_cfg(level).lazy;  // levels 1-3
   // lazy levels, streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS, any length)
   const bool seg_links = need_lz && !greedy && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds;
-  const uint32_t seg_runs = (uint32_t)((((size_t)vd + max_in_len + kSegG - 1) / kSegG + kSegRun - 1) / kSegRun);
+  // (a workgroup takes a run of consecutive segments: whole streams when there are streams enough to fill the
+  // chip -- up to 64 segments, 2 MiB -- else runs of kSegRun, whose first segment is sorted twice)
+  const uint32_t seg_max = (uint32_t)(((size_t)vd + max_in_len + kSegG - 1) / kSegG);
+  const uint32_t seg_run_len = (count >= 1024 && seg_max <= 64) ? std::max(seg_max, 1u) : kSegRun;
+  const uint32_t seg_runs = (seg_max + seg_run_len - 1) / seg_run_len;
   // the rest (greedy levels, short streams, V alone for level 0 / huffman_only): k_sort_links, in LDS when V fits there
   const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
   const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 24ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
@@ -345,7 +349,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     }
     // V (and, for the match search, the trigram chains)
     if (seg_links)
-      LAUNCH("k_seg_links", k_seg_links, c * seg_runs, kSegThreads, kSegLdsBytes, B, seg_runs);
+      LAUNCH("k_seg_links", k_seg_links, c * seg_runs, kSegThreads, kSegLdsBytes, B, seg_runs, seg_run_len);
     else if (B.sort_lds && B.sort_lds <= kSortNarrowMaxLds)
       LAUNCH("k_sort_links", (k_sort_links<true, kSortThreadsNarrow>), c, kSortThreadsNarrow, B.sort_lds, B);
     else if (B.sort_lds)
