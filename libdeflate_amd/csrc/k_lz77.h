@@ -407,6 +407,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
   __shared__ uint16_t s_cnt[kSegWaves][256];
   __shared__ uint16_t s_pre[kSegWaves][256];
   __shared__ uint32_t s_tot[16];
+  __shared__ uint32_t s_top;
   __shared__ uint32_t s_lcnt[kSegItems * kSegWaves];  // list entries per (row of 1024, wave), then where they go
   __shared__ uint32_t sK[kSegPiece];  // a piece of the previous segment's list
   __shared__ uint16_t sP[kSegPiece];
@@ -428,6 +429,8 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
   const uint32_t g_end = g_first + run_len < nseg ? g_first + run_len : nseg;
   const bool in_aligned = (((uintptr_t)in - D) & 3) == 0;
   for (uint32_t i = tid; i < kSegWaves * 256; i += kSegThreads) (&s_cnt[0][0])[i] = 0;
+  if (tid == 0) s_top = 0;
+  __syncthreads();
 
   uint32_t nprev = 0;  // entries of the list the previous iteration left
   for (uint32_t g = g_first ? g_first - 1 : 0; g < g_end; g++) {
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
       // usual case): all of a thread's loads in flight at once -- one workgroup per CU has nothing else
       // to hide them behind (a load, a store and the next load in turn took 0.9 of the kernel's 11.6 ms)
       const uint32_t nw = total / 4;
+      uint32_t any_bits = 0;
       const bool dict_al = (((uintptr_t)B.dict) & 3) == 0;
       // 1: a dword of the dictionary, 2: of the input, 0: bytes (an edge, or nothing aligned)
       auto kind = [&](uint32_t idx) -> uint32_t {
@@ -476,6 +480,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
             if (idx * 4 < wlimit) *(uint32_t *)(Vg + lo + idx * 4) = wd[i];
             *(uint32_t *)(Vs + idx * 4) = wd[i];
           }
+          any_bits |= wd[i];
         }
       }
       for (uint32_t idx = ts; idx < nw; idx += kSegThreads) {  // the rest byte by byte
@@ -491,9 +496,13 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
         }
         if (w < wlimit) *(uint32_t *)(Vg + lo + w) = word;
         *(uint32_t *)(Vs + w) = word;
+        any_bits |= word;
       }
+      // (text: no byte of the segment has its top bit set, and the passes rank by seven bits)
+      if (__builtin_amdgcn_ballot_w64((any_bits & 0x80808080u) != 0) && lane == 0) s_top = 1;
     }
     __syncthreads();
+    const bool top_bit = s_top != 0;
 
 #ifdef LDH_SEG_STOP  // profiling builds only (-DLDH_SEG_STOP=n: skip what follows stage n; results are wrong)
     if (LDH_SEG_STOP == 1) continue;
@@ -502,8 +511,9 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
     // [w*per*64, (w+1)*per*64), row j of them is one element per lane.  FULL: a whole segment, nothing to
     // check per element or per row (a sixth of the instructions, and the rows' digit reads are no longer
     // fenced in by branches).
-    auto sort_passes = [&](auto full_tag) {
+    auto sort_passes = [&](auto full_tag, auto bits_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
+      constexpr int BITS = decltype(bits_tag)::value;
       const uint32_t per = FULL ? (uint32_t)kSegItems : (m + kSegThreads - 1) / kSegThreads;
 #pragma unroll 1
       for (int pass = 0; pass < 3; pass++) {
@@ -532,15 +542,15 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
           if (FULL || (uint32_t)j < per) {
             const bool valid = FULL || (e[j] & 0xFFFFu) != 0xFFFFu;
             const uint32_t d = e[j] >> 16;
-            uint32_t xlo = 0, xhi = 0;  // lanes whose digit differs from mine in some bit (see k_sort_links)
+            uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;  // lanes whose digit agrees with mine in every bit so far
 #pragma unroll
-            for (int bit = 0; bit < 8; bit++) {
-              const uint32_t mk = (uint32_t)((int32_t)(d << (31 - bit)) >> 31);
+            for (int bit = 0; bit < BITS; bit++) {
+              const uint32_t mk = (uint32_t)((int32_t)(d << (31 - bit)) >> 31);  // all ones: my bit is set
               const unsigned long long bal = __builtin_amdgcn_ballot_w64((int32_t)mk < 0);
-              xlo = __builtin_amdgcn_bitop3_b32(xlo, (uint32_t)bal, mk, 0xF6);
-              xhi = __builtin_amdgcn_bitop3_b32(xhi, (uint32_t)(bal >> 32), mk, 0xF6);
+              // m &= ~(bal ^ mk), one v_bitop3 per half (truth table of a & ~(b ^ c))
+              mlo = __builtin_amdgcn_bitop3_b32(mlo, (uint32_t)bal, mk, 0x90);
+              mhi = __builtin_amdgcn_bitop3_b32(mhi, (uint32_t)(bal >> 32), mk, 0x90);
             }
-            uint32_t mlo = ~xlo, mhi = ~xhi;
             if (!FULL) {  // (lanes without an element vote with digit 0 and are masked out here)
               const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
               mlo &= (uint32_t)vm;
@@ -597,10 +607,12 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
         __syncthreads();
       }
     };
-    if (m == kSegG)
-      sort_passes(std::true_type{});
+    if (m == kSegG && !top_bit)
+      sort_passes(std::true_type{}, std::integral_constant<int, 7>{});
+    else if (m == kSegG)
+      sort_passes(std::true_type{}, std::integral_constant<int, 8>{});
     else
-      sort_passes(std::false_type{});
+      sort_passes(std::false_type{}, std::integral_constant<int, 8>{});
 
     // neighbours in sorted order: element r = j*1024 + tid; res = position | link << 15 | first << 30 | last << 31.
     // A lane gets its neighbours' trigrams from the lanes beside it; what the ends of a row of 64 need from
@@ -765,6 +777,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
       asm volatile("" : "+v"(t_));
       for (uint32_t i = t_; i < (m + 1) / 2; i += kSegThreads) dst32[i] = src32[i];
     }
+    if (tid == 0) s_top = 0;  // (read before the passes; set again behind the next staging's barrier)
     __syncthreads();
     nprev = want_list ? ntot : 0u;
   }
