@@ -248,7 +248,7 @@ def main():
         value = in_bytes / dt / 1e9
         # dominant kernel of the timed region
         name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
-        compress_kernels = ("k_sort_links", "k_match_lazy", "k_parse_lazy", "k_lz_greedy", "k_tokens_literal",
+        compress_kernels = ("k_sort_links", "k_seg_links", "k_match_lazy", "k_parse_lazy", "k_lz_greedy", "k_tokens_literal",
                             "k_histogram", "k_huffman", "k_plan", "k_bitpack")
         # algorithmic bytes per launch: compress N_in + N_out, decompress N_comp + N_out
         alg = S * L + comp_bytes
