@@ -340,7 +340,10 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // capacity below 2^32: lengths are reported as uint32 anyway), and the bit position is a
 // 32-bit offset `rel` into the staged window plus a 64-bit base that changes only when the
 // window is reloaded.
-__device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
+// (not inlined on purpose: inlined at its two call sites it shares k_inflate's scalar registers with the header code
+// around it, and the round loop reloaded spilled ones through v_readlane / v_writelane -- 11.0 -> 10.6 ms per GiB as a
+// function of its own: 70 SGPRs, 56 VGPRs, one call per deflate block)
+__device__ __attribute__((noinline)) int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
                             uint32_t *s_in /* LDS, 64 + 4 dwords */, uint32_t *s_tk /* LDS, 64 dwords */) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
