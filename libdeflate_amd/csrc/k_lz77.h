@@ -801,6 +801,9 @@ constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
 #define LDH_MATCH_STEPS 8
 #endif
 
+#ifndef LDH_MATCH_WALKS
+#define LDH_MATCH_WALKS 1
+#endif
 #ifndef LDH_REFILL_MIN_DEEP
 #define LDH_REFILL_MIN_DEEP 12
 #endif
@@ -878,14 +881,21 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   //   seed   (dictionary) lanes whose walk has taken a candidate in the last two dictionary
   //          bytes, after which LD:1394 lets it go no deeper into the dictionary
   constexpr uint32_t steps_per_round = kMatchSteps;
-  unsigned long long act = 0, pm = 0, pend = 0, seed = 0;
+  // NW walks per lane (LDH_MATCH_WALKS).  With 31 registers the kernel has room for a second, independent walk in every
+  // lane whose LDS round trips overlap the first one's -- measured: 22.7 ms per GiB against 21.6 with one.  The kernel
+  // is bound by throughput (VALU 84 % and LDS 80 % busy), not by latency; two walks only lengthen the drain.
+  constexpr int NW = LDH_MATCH_WALKS;
+  struct Walk {
+    unsigned long long act = 0, pm = 0, pend = 0, seed = 0;
+    uint32_t q = 0, vb = 0, cb = 0, maxlen = 0, t2 = 0, dn = 0xFFFFu;
+    uint32_t res = 0;  // best length << 16 | its distance: the word that is stored; 0 = no match yet
+    uint32_t d1 = 0;   // candidates the walk may still evaluate after the current one (LD:1362)
+    uint32_t off = 0;  // best ? best - 1 : 0
+    int32_t lo = 0;    // vb - 32768: the farthest candidate inside the window (LD:1365)
+    uint64_t tw = 0;
+  };
+  Walk w[NW];
   bool exhausted = false;
-  uint32_t q = 0, vb = 0, cb = 0, maxlen = 0, t2 = 0, dn = 0xFFFFu;
-  uint32_t res = 0;  // best length << 16 | its distance: the word that is stored; 0 = no match yet
-  uint32_t d1 = 0;   // candidates the walk may still evaluate after the current one (LD:1362)
-  uint32_t off = 0;  // best ? best - 1 : 0
-  int32_t lo = 0;    // vb - 32768: the farthest candidate inside the window (LD:1365)
-  uint64_t tw = 0;
   const uint64_t lane_bit = 1ull << lane;
 
   // x -= 1 in the lanes of a wave-uniform mask: one subtract-with-borrow whose borrow-in is the
@@ -896,59 +906,56 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     asm("v_subbrev_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(x_), "=s"(bo_) : "s"(m_));                \
   }
   // hop from candidate cb over link dn_ for the lanes in cond_; returns the lanes that go on
-#define LDH_HOP(cond_, dn_, go_)                                                                  \
+#define LDH_HOP(W_, cond_, dn_, go_)                                                              \
   {                                                                                               \
-    const unsigned long long more_ = ballot64(d1 != 0);                                           \
-    LDH_DEC_MASKED(d1, cond_);                                                                    \
-    const uint32_t cn_ = cb - (dn_);                                                              \
-    go_ = (cond_) & more_ & ballot64((int32_t)cn_ >= lo);                                         \
+    const unsigned long long more_ = ballot64(W_.d1 != 0);                                        \
+    LDH_DEC_MASKED(W_.d1, cond_);                                                                 \
+    const uint32_t cn_ = W_.cb - (dn_);                                                           \
+    go_ = (cond_) & more_ & ballot64((int32_t)cn_ >= W_.lo);                                      \
     if (HAS_DICT) { /* dictionary side of V (Q10) */                                              \
       const uint32_t c_ = cn_ + wbase;                                                            \
       const unsigned long long in_dict_ = ballot64(c_ < D), deep_ = ballot64(c_ + 2 < D);         \
-      go_ &= ~(in_dict_ & deep_ & seed);                                                          \
-      seed |= go_ & in_dict_ & ~deep_;                                                            \
+      go_ &= ~(in_dict_ & deep_ & W_.seed);                                                       \
+      W_.seed |= go_ & in_dict_ & ~deep_;                                                         \
     }                                                                                             \
-    cb = __builtin_amdgcn_inverse_ballot_w64(go_) ? cn_ : cb;                                     \
+    W_.cb = __builtin_amdgcn_inverse_ballot_w64(go_) ? cn_ : W_.cb;                               \
   }
 
   // ---- batched full compare of the candidates that passed the quick reject
-  auto compare = [&]() {
-    const unsigned long long cm = act & pm;
-    pm = 0;
+  auto compare = [&](Walk &W) {
+    const unsigned long long cm = W.act & W.pm;
+    W.pm = 0;
     if (cm) {
       if (cm & lane_bit) {
-        const uint64_t x = lds_load8(lbytes, cb + 3) ^ tw;
+        const uint64_t x = lds_load8(lbytes, W.cb + 3) ^ W.tw;
         uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
         // the tail of a long match, 8 bytes per trip: a wave-uniform loop over the lanes still equal
         // (per-lane `break`s cost some 25 scalar instructions of mask bookkeeping per trip)
-        unsigned long long going = ballot64((x == 0) & (L < maxlen));
+        unsigned long long going = ballot64((x == 0) & (L < W.maxlen));
         while (going) {  // (bytes are staged 280 past the tile's end: reading past maxlen is safe)
           const bool on = __builtin_amdgcn_inverse_ballot_w64(going);
-          const uint64_t y = lds_load8(lbytes, cb + L) ^ lds_load8(lbytes, vb + L);
+          const uint64_t y = lds_load8(lbytes, W.cb + L) ^ lds_load8(lbytes, W.vb + L);
           const uint32_t adv = y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8u;
           L += on ? adv : 0u;
-          going &= ballot64((y == 0) & (L < maxlen));
+          going &= ballot64((y == 0) & (L < W.maxlen));
         }
-        if (L > maxlen) L = maxlen;
-        if ((L << 16) > res) {  // L > best (distances are below 65536); LD:1385 strict: nearest of equal lengths wins
-          res = (L << 16) | (vb - cb);
-          off = L - 1;
-          t2 = lds_load2(lbytes, vb + off);
+        if (L > W.maxlen) L = W.maxlen;
+        if ((L << 16) > W.res) {  // L > best (distances are below 65536); LD:1385 strict: nearest of equal lengths wins
+          W.res = (L << 16) | (W.vb - W.cb);
+          W.off = L - 1;
+          W.t2 = lds_load2(lbytes, W.vb + W.off);
         }
       }
       // a match of maxlen cannot be beaten (the walk has no side effects, so ending it early
       // leaves the result unchanged)
-      const unsigned long long open = ballot64(((res >> 16) < nice) & ((res >> 16) < maxlen));
+      const unsigned long long open = ballot64(((W.res >> 16) < nice) & ((W.res >> 16) < W.maxlen));
       unsigned long long go;
-      LDH_HOP(cm & open, dn, go);
-      act = (act & ~cm) | go;
+      LDH_HOP(W, cm & open, W.dn, go);
+      W.act = (W.act & ~cm) | go;
     }
   };
-  // ---- refill idle lanes
-  auto refill = [&](unsigned long long idle, uint32_t nidle) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&s_next, nidle);
-    base = __builtin_amdgcn_readfirstlane(base);
+  // ---- refill idle lanes: positions [base, base + nidle) go to the idle lanes of W in lane order
+  auto refill = [&](Walk &W, unsigned long long idle, uint32_t base) {
     // (The new walk state is computed by every lane -- lanes that are not idle from a clamped
     // position -- and taken over by the idle ones in one exec-masked block of plain moves: with
     // the loads inside a branch the compiler copies all twelve state registers on both sides of
@@ -956,7 +963,7 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     // gets no position or one that is not searched (LD:1349): that one keeps best = 0 and is
     // stored like any other result at the lane's next refill.)
     const bool mine = (idle & lane_bit) != 0;
-    if (mine && (pend & lane_bit)) mout[q] = res;
+    if (mine && (W.pend & lane_bit)) mout[W.q] = W.res;
     const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
     const bool has_pos = mine & (my < q1);
     const uint32_t myc = has_pos ? my : q0;  // (keeps the LDS addresses below inside the staged range)
@@ -970,29 +977,28 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     const uint32_t t2n = lds_load2(lbytes, vbn);
     const uint32_t dnn = lprev[cbn];
     if (mine) {
-      q = myc;
-      vb = vbn;
-      lo = (int32_t)vbn - (int32_t)kWindow;
-      cb = cbn;
-      maxlen = mln > kMaxMatch ? kMaxMatch : mln;
-      tw = twn;
-      t2 = t2n;
-      d1 = (uint32_t)cfg.max_chain - 1;  // Q3
-      res = 0u;
-      off = 0u;
-      dn = dnn;
+      W.q = myc;
+      W.vb = vbn;
+      W.lo = (int32_t)vbn - (int32_t)kWindow;
+      W.cb = cbn;
+      W.maxlen = mln > kMaxMatch ? kMaxMatch : mln;
+      W.tw = twn;
+      W.t2 = t2n;
+      W.d1 = (uint32_t)cfg.max_chain - 1;  // Q3
+      W.res = 0u;
+      W.off = 0u;
+      W.dn = dnn;
     }
     // LD:1349 (the last two positions of a block are not searched); chain empty (0xFFFF) / LD:1365
     const bool started = has_pos & (p + 2 <= be) & (d0 <= kWindow);
     const unsigned long long st = ballot64(started);
-    act |= st;
+    W.act |= st;
     // the first candidate of a chain always passes the reject (best = 0: the bytes tested are
     // the trigram's): hand it to the full compare at once instead of freezing the lane on it
     // for a round
-    pm |= st;
-    pend = (pend & ~idle) | ballot64(has_pos);
-    if (HAS_DICT) seed = (seed & ~idle) | (st & ballot64((cb + wbase < D) & !(cb + wbase + 2 < D)));
-    if (base + nidle >= q1) exhausted = true;
+    W.pm |= st;
+    W.pend = (W.pend & ~idle) | ballot64(has_pos);
+    if (HAS_DICT) W.seed = (W.seed & ~idle) | (st & ballot64((W.cb + wbase < D) & !(W.cb + wbase + 2 < D)));
   };
 
   // ---- chain steps: one LDS round trip each (link of the candidate + its reject bytes).
@@ -1001,11 +1007,15 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   auto steps = [&]() {
 #pragma unroll
     for (uint32_t step = 0; step < steps_per_round; step++) {
-      dn = lprev[cb];
-      pm = ballot64(lds_load2(lbytes, cb + off) == t2);
-      unsigned long long go;
-      LDH_HOP(act & ~pm, dn, go);
-      act = (act & pm) | go;
+#pragma unroll
+      for (int i = 0; i < NW; i++) {
+        Walk &W = w[i];
+        W.dn = lprev[W.cb];
+        W.pm = ballot64(lds_load2(lbytes, W.cb + W.off) == W.t2);
+        unsigned long long go;
+        LDH_HOP(W, W.act & ~W.pm, W.dn, go);
+        W.act = (W.act & W.pm) | go;
+      }
     }
   };
 
@@ -1013,20 +1023,44 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   // finish per round, so a threshold saved little and its branch cost a register shuffle on
   // both sides); then the walks in flight drain.
   while (!exhausted) {
-    const unsigned long long idle = ~act;
-    const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (REFILL_MIN <= 1 || nidle >= (uint32_t)REFILL_MIN) refill(idle, nidle);
-    compare();
+    unsigned long long idle[NW];
+    uint32_t nidle[NW], total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      idle[i] = ~w[i].act;
+      nidle[i] = (uint32_t)__popcll(idle[i]);
+      total += nidle[i];
+    }
+    if (REFILL_MIN <= 1 || total >= (uint32_t)REFILL_MIN * NW) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_next, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int i = 0; i < NW; i++) {
+        refill(w[i], idle[i], base);
+        base += nidle[i];
+      }
+      if (base >= q1) exhausted = true;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; i++) compare(w[i]);
     steps();
   }
   for (;;) {
-    compare();
-    if (!act) break;
+    unsigned long long any = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      compare(w[i]);
+      any |= w[i].act;
+    }
+    if (!any) break;
     steps();
   }
 #undef LDH_HOP
 #undef LDH_DEC_MASKED
-  if (pend & lane_bit) mout[q] = res;
+#pragma unroll
+  for (int i = 0; i < NW; i++)
+    if (w[i].pend & lane_bit) mout[w[i].q] = w[i].res;
 }
 
 // ------------------------------------------------------------------ k_parse_lazy
