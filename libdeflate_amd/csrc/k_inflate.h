@@ -340,10 +340,8 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
 // capacity below 2^32: lengths are reported as uint32 anyway), and the bit position is a
 // 32-bit offset `rel` into the staged window plus a 64-bit base that changes only when the
 // window is reloaded.
-// (not inlined on purpose: inlined at its two call sites it shares k_inflate's scalar registers with the header code
-// around it, and the round loop reloaded spilled ones through v_readlane / v_writelane -- 11.0 -> 10.6 ms per GiB as a
-// function of its own: 70 SGPRs, 56 VGPRs, one call per deflate block)
-__device__ __attribute__((noinline)) int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
+template <int COPY>  // (0: the copy that is called, 1: the copy that is inlined; see k_inflate below)
+__device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t lane,
                             uint32_t *s_in /* LDS, 64 + 4 dwords */, uint32_t *s_tk /* LDS, 64 dwords */) {
   uint32_t ext = 0;
   if (O.dict && !O.dict_loaded) {  // LD:2367-2377
@@ -535,12 +533,16 @@ __device__ __attribute__((noinline)) int decode_block(const LitTab &LT, const Di
   }
 }
 
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate(InflateArgs A) {
-  __shared__ LitTab LT;
-  __shared__ DistTab DT;
-  __shared__ uint8_t lens[320 + 32];
-  __shared__ uint32_t s_in[kWave + 4];
-  __shared__ uint32_t s_tk[kWave];
+// The block body as a function of its own.  Inlined at its two call sites it shares k_inflate's scalar registers
+// with the header code around it, and the round loop reloads spilled ones through v_readlane / v_writelane: with the
+// chip full of waves (instruction issue is the bound) the call is faster, 11.0 -> 10.6 ms per GiB at 8192 streams
+// (70 SGPRs, 56 VGPRs of its own, one call per deflate block); a wave that runs alone is bound by latency and is
+// faster with the inlined body (one 16 MiB stream: 520 against 570 ms).  Hence two kernels, chosen by batch size
+// (the call is kept a call by a statement attribute; a noinline wrapper around the inlinable body sent this
+// compiler's backend into "Illegal instruction detected" on the LDS pointers' address-space casts).
+template <bool BODY_CALL>
+__device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT, DistTab &DT, uint8_t *lens, uint32_t *s_in,
+                                               uint32_t *s_tk) {
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
   const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
@@ -602,7 +604,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           build_table(DT, lens + 288, 32, 5, DistTab::kBits, lane, kLutDist);
           fixed_ready = 1;
         }
-        status = decode_block(LT, DT, R, O, lane, s_in, s_tk);
+        if (BODY_CALL) {
+          [[clang::noinline]] status = decode_block<0>(LT, DT, R, O, lane, s_in, s_tk);
+        } else {
+          status = decode_block<1>(LT, DT, R, O, lane, s_in, s_tk);
+        }
       } else if (type == 2) {  // LD:2506-2615
         fixed_ready = 0;
         const uint32_t nlen = br_read(R, 5, lane) + 257;
@@ -660,7 +666,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
         err = build_table(DT, lens + 320, (int)ndist, 15, DistTab::kBits, lane, kLutDist);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
-        status = decode_block(LT, DT, R, O, lane, s_in, s_tk);
+        if (BODY_CALL) {
+          [[clang::noinline]] status = decode_block<0>(LT, DT, R, O, lane, s_in, s_tk);
+        } else {
+          status = decode_block<1>(LT, DT, R, O, lane, s_in, s_tk);
+        }
       } else {
         status = -1;
       }
@@ -681,6 +691,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (A.expect_adler) A.expect_adler[s] = expect;
   }
 }
+
+// (two plain kernels rather than one template: with the LDS arrays inside a kernel template this compiler's backend
+// stopped with "Illegal instruction detected" on their address-space casts)
+#define LDH_INFLATE_KERNEL(name_, call_)                                                                      \
+  __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void name_(InflateArgs A) {  \
+    __shared__ LitTab LT;                                                                                     \
+    __shared__ DistTab DT;                                                                                    \
+    __shared__ uint8_t lens[320 + 32];                                                                        \
+    __shared__ uint32_t s_in[kWave + 4];                                                                      \
+    __shared__ uint32_t s_tk[kWave];                                                                          \
+    inflate_stream<call_>(A, LT, DT, lens, s_in, s_tk);                                                       \
+  }
+LDH_INFLATE_KERNEL(k_inflate, true)         // the block body as a call: batches that fill the chip
+LDH_INFLATE_KERNEL(k_inflate_alone, false)  // inlined: few streams
+#undef LDH_INFLATE_KERNEL
 
 // DecompressZlibInternal's final comparison (LD:2717-2722)
 __global__ void k_zlib_check(uint32_t count, const uint32_t *expect, const uint32_t *actual,

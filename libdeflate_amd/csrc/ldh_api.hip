@@ -392,7 +392,10 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     }
     if (fmt == 1)
       LAUNCH("k_adler32", k_adler32, c, kAdlerThreads, 0, d_in, B.in_off, (uint64_t)0, (const uint32_t *)nullptr, B.adler);
-    LAUNCH("k_plan", k_plan, (c + 63) / 64, 64, 0, Bz);
+    if (max_blocks > 16)  // streams beyond 1 MiB: a wavefront per stream
+      LAUNCH("k_plan", k_plan_wave, c, kWave, 0, Bz);
+    else
+      LAUNCH("k_plan", k_plan, (c + 63) / 64, 64, 0, Bz);
     LAUNCH("k_bitpack", k_bitpack, c * max_blocks, kPackThreads, 0, Bz);
     HIPCHK(hipGetLastError());
     cx.last = B;
@@ -436,7 +439,12 @@ int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off
   A.bytes_left = d_bytes_left;
   A.status = d_status;
   A.expect_adler = expect;
-  LAUNCH("k_inflate", k_inflate, (uint32_t)count, kWave, 0, A);
+  // (the block body as a call when the batch fills the chip with waves, inlined when they run nearly alone)
+  static const int body_call_min = getenv("LDH_INFLATE_CALL_MIN") ? atoi(getenv("LDH_INFLATE_CALL_MIN")) : 4096;
+  if (count >= (size_t)body_call_min)
+    LAUNCH("k_inflate", k_inflate, (uint32_t)count, kWave, 0, A);
+  else
+    LAUNCH("k_inflate", k_inflate_alone, (uint32_t)count, kWave, 0, A);
   if (fmt == 1) {
     LAUNCH("k_adler32", k_adler32, (uint32_t)count, kAdlerThreads, 0, (const uint8_t *)d_out,
            (const uint64_t *)nullptr, (uint64_t)out_stride, (const uint32_t *)d_out_len, actual);

@@ -202,6 +202,34 @@ def test_usage_errors_that_need_the_device_T2351(LD):
         assert str(e.value) == "Usage: LibDeflate:%s(str): 'str' - string expected got 'nil'." % name
 
 
+def test_block_plan_of_long_streams(LD, B):
+    # streams beyond 1 MiB are planned by a wavefront (k_plan_wave): runs of blocks evaluated for the eight bit
+    # phases a run can be entered at, then chained.  The phase only matters through stored blocks (their padding,
+    # which can tip the choice of type), so: incompressible stretches between text (stored blocks at odd bit
+    # positions, at level 5), level 0 (stored only), forced strategies, zlib framing with its 16 / 48 header bits
+    from libdeflate_amd import synth
+    rng = np.random.default_rng(11)
+    text = b"".join(r.tobytes() for r in synth.text_streams(12, 131072))
+    noise = rng.integers(0, 256, 400000, dtype=np.uint8).tobytes()
+    mixed = text[:300001] + noise[:131071] + text[300001:700000] + noise[131071:] + text[700000:1100003]
+    assert len(mixed) > 17 * 65536
+    streams = [mixed, mixed[:1200000], text[:1500000], b"tail"]
+    for level in (5, 0):
+        for s, g in zip(streams, B.compress_batch(streams, level=level)):
+            assert g == o_compress(s, level=level), (level, len(s))
+    for strategy in ("fixed", "dynamic", "huffman_only"):
+        got = B.compress_batch(streams[:2], level=4, strategy=strategy)
+        for s, g in zip(streams[:2], got):
+            assert g == o_compress(s, level=4, strategy=strategy), (strategy, len(s))
+    dct = golden("dictionary32768.txt")
+    d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
+    for s, g in zip(streams[:2], B.compress_batch(streams[:2], fmt=1, level=5, dictionary=d)):
+        assert g == o_compress(s, zlib=True, level=5, dict=dct), len(s)
+    got = B.compress_batch(streams, fmt=1, level=6)
+    back = B.decompress_batch([c for c, _ in got], fmt=1, max_out=len(mixed))
+    assert [x for x, _ in back] == streams
+
+
 def test_pool_of_two_contexts_on_device_0(LD, B):
     # one library, many GPUs.  The box has one GPU, so the pool is two contexts on device 0:
     # the host-pointer batch calls split their streams by bytes over both (two host threads, two sets of streams and
