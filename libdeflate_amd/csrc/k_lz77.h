@@ -820,52 +820,73 @@ constexpr uint32_t kMatchSteps = LDH_MATCH_STEPS;  // chain steps between two lo
 // them spent in the drain at the tile's end; with its few KB of LDS eight of the small workgroups share a CU).
 // lds_byte_cap: bytes of LDS set aside for the staged bytes (a multiple of 4); the links follow them.
 template <bool HAS_DICT, int REFILL_MIN, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_per_stream, uint32_t lds_byte_cap) {
+__global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_per_stream, uint32_t lds_byte_cap,
+                                                        uint32_t tiles_per_wg) {
   constexpr int kMatchThreads = THREADS;
   extern __shared__ uint32_t smem[];
   uint32_t *lbytes = smem;                                  // lds_byte_cap bytes
   uint16_t *lprev = (uint16_t *)(smem + lds_byte_cap / 4);  // window + tile + 8 entries
   __shared__ uint32_t s_next;
 
+  // A workgroup takes `tiles_per_wg` consecutive tiles of one stream: from the second one on, the window it needs is
+  // mostly in LDS already (the last 32768 positions of what the tile before had staged), is moved down there, and
+  // only the new tile's bytes and links come from memory (60 KB instead of 160: staging was 1.6 of the kernel's
+  // 21.6 ms per GiB).
+  const uint32_t runs_per_stream = (tiles_per_stream + tiles_per_wg - 1) / tiles_per_wg;
   const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
-  const uint32_t s = work / tiles_per_stream, tile = work % tiles_per_stream;
+  const uint32_t s = work / runs_per_stream, tile_first = (work % runs_per_stream) * tiles_per_wg;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t n = stream_len(B, s), D = HAS_DICT ? B.dlen : 0;
-  const uint32_t q0 = tile * kTile;
-  if (q0 >= n) return;
-  const uint32_t q1 = (q0 + kTile < n) ? q0 + kTile : n;  // stream positions [q0, q1) 0-based
+  if (tile_first * kTile >= n) return;
   const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
   const uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
   uint32_t *mout = B.bufB + (size_t)s * B.nvp;
   const LevelCfg cfg = level_cfg(B.level);
   const uint32_t nice = (uint32_t)cfg.nice;
+  const uint32_t alloc_end = D + n + kVPad;  // bytes valid in vbuf
 
-  const uint32_t v0 = q0 + D, v1 = q1 + D;
-  const uint32_t wbase = (v0 > kWindow ? v0 - kWindow : 0) & ~3u;
-  {  // stage bytes [wbase, v1 + 280) (zero beyond the allocated pad) and links [wbase, v1)
-    const uint32_t alloc_end = D + n + kVPad;  // bytes valid in vbuf
+  // the current tile: stream positions [q0, q1) 0-based = V positions [v0, v1); LDS holds bytes
+  // [wbase, v1 + 280) (zero beyond the allocated pad) and links [wbase, v1)
+  uint32_t q0 = tile_first * kTile, q1 = 0, v0 = 0, v1 = 0, wbase = 0, be_lo = 0, be_hi = 0;
+  // dwords [b_from, ..) of the bytes and [p_from, ..) of the links, relative to wbase, from memory
+  auto stage = [&](uint32_t b_from, uint32_t p_from) {
     const uint32_t nb = (v1 + 280 - wbase + 3) / 4;
     const uint32_t *gsrc = (const uint32_t *)(V + wbase);
-    for (uint32_t i = tid; i < nb; i += kMatchThreads)
+    for (uint32_t i = b_from + tid; i < nb; i += kMatchThreads)
       lbytes[i] = (wbase + 4 * i + 4 <= alloc_end) ? gsrc[i] : 0u;
     // "no link" (0) becomes 0xFFFF: a hop of 65535 always fails the window test, so the chain
     // step needs no separate end-of-chain compare
     const uint32_t np = (v1 - wbase + 1) / 2;
     const uint32_t *psrc = (const uint32_t *)(prevd + wbase);
     uint32_t *pdst = (uint32_t *)lprev;
-    for (uint32_t i = tid; i < np; i += kMatchThreads) {
+    for (uint32_t i = p_from + tid; i < np; i += kMatchThreads) {
       uint32_t x = psrc[i];
       x |= (x & 0xFFFFu) ? 0u : 0xFFFFu;
       x |= (x >> 16) ? 0u : 0xFFFF0000u;
       pdst[i] = x;
     }
-    if (tid == 0) s_next = q0;
-  }
+  };
+  // what tile (q0_) needs staged
+  auto set_tile = [&](uint32_t q0_) {
+    q0 = q0_;
+    q1 = (q0 + kTile < n) ? q0 + kTile : n;
+    v0 = q0 + D;
+    v1 = q1 + D;
+    wbase = (v0 > kWindow ? v0 - kWindow : 0) & ~3u;
+    // a tile (at most 20480 positions) straddles at most one deflate-block end (they are 32768 apart)
+    const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
+    be_lo = block_end(blk0, n);
+    be_hi = block_end(blk0 + 1, n);
+  };
+  set_tile(q0);
+  stage(0, 0);
+  if (tid == 0) s_next = q0;
   __syncthreads();
 
-  // a tile (at most 20480 positions) straddles at most one deflate-block end (they are 32768 apart)
-  const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
-  const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
+#ifdef LDH_MATCH_STOP  // profiling builds only: the staging alone
+  if (lbytes[tid] == 0x12345678u) mout[q0] = lprev[tid];
+  return;
+#endif
 
   // Instruction issue bounds this loop (a wave64 VALU op holds its SIMD for 4 cycles, the
   // CU's one scalar unit issues one instruction per cycle), so the chain step is written to
@@ -1022,6 +1043,7 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   // While the tile has positions left every round refills whatever is idle (about 17 lanes
   // finish per round, so a threshold saved little and its branch cost a register shuffle on
   // both sides); then the walks in flight drain.
+  for (uint32_t tile = tile_first;;) {
   while (!exhausted) {
     unsigned long long idle[NW];
     uint32_t nidle[NW], total = 0;
@@ -1046,6 +1068,31 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     for (int i = 0; i < NW; i++) compare(w[i]);
     steps();
   }
+  // (the next tile's new bytes and links are fetched into registers now and arrive while the walks in flight drain)
+  constexpr uint32_t kNewB = (kTile / 4 + THREADS - 1) / THREADS + 1, kNewP = (kTile / 2 + THREADS - 1) / THREADS + 1;
+  uint32_t nwb[kNewB], nwp[kNewP];
+  uint32_t kbN = 0, kpN = 0, nbN = 0, npN = 0;
+  const bool more = THREADS >= 1024 && tile + 1 < tile_first + tiles_per_wg && (tile + 1) * kTile < n;
+  if (more) {
+    const uint32_t q0n = (tile + 1) * kTile, q1n = (q0n + kTile < n) ? q0n + kTile : n;
+    const uint32_t v0n = q0n + D, v1n = q1n + D, wbn = (v0n > kWindow ? v0n - kWindow : 0) & ~3u;
+    kbN = (v1 + 280 - wbn) / 4;  // whole dwords of the bytes / links that stay (v1 = v0n)
+    kpN = (v1 - wbn) / 2;
+    nbN = (v1n + 280 - wbn + 3) / 4;
+    npN = (v1n - wbn + 1) / 2;
+    const uint32_t *gsrc = (const uint32_t *)(V + wbn);
+    const uint32_t *psrc = (const uint32_t *)(prevd + wbn);
+#pragma unroll
+    for (uint32_t k = 0; k < kNewB; k++) {
+      const uint32_t i = kbN + k * kMatchThreads + tid;
+      nwb[k] = (i < nbN && wbn + 4 * i + 4 <= alloc_end) ? gsrc[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kNewP; k++) {
+      const uint32_t i = kpN + k * kMatchThreads + tid;
+      nwp[k] = i < npN ? psrc[i] : 0u;
+    }
+  }
   for (;;) {
     unsigned long long any = 0;
 #pragma unroll
@@ -1056,11 +1103,74 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     if (!any) break;
     steps();
   }
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    if (w[i].pend & lane_bit) mout[w[i].q] = w[i].res;
+    w[i].pend = 0;
+    w[i].pm = 0;
+    if (HAS_DICT) w[i].seed = 0;
+  }
+  // ---- the next tile of the run
+  if (!more) break;
+  tile++;
+  {
+    const uint32_t wb_old = wbase, v1_old = v1;
+    __syncthreads();  // every walk of the tile has ended
+    set_tile(tile * kTile);
+    const uint32_t sh = wbase - wb_old;  // positions the window moves on: a multiple of 4
+    // what stays: bytes [wbase, v1_old + 280) and links [wbase, v1_old), through registers (the ranges overlap)
+    const uint32_t kb = (v1_old + 280 - wbase) / 4, kp = (v1_old - wbase) / 2;  // whole dwords kept
+    if (sh) {
+      constexpr uint32_t kMaxB = (kWindow + 288 + 4 * THREADS - 1) / (4 * THREADS) + 1;
+      constexpr uint32_t kMaxP = (kWindow + 2 * THREADS - 1) / (2 * THREADS) + 1;
+      uint32_t rb[kMaxB], rp[kMaxP];
+      uint32_t *pdst = (uint32_t *)lprev;
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxB; k++) {
+        const uint32_t i = k * kMatchThreads + tid;
+        rb[k] = i < kb ? lbytes[i + sh / 4] : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxP; k++) {
+        const uint32_t i = k * kMatchThreads + tid;
+        rp[k] = i < kp ? pdst[i + sh / 2] : 0u;
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxB; k++) {
+        const uint32_t i = k * kMatchThreads + tid;
+        if (i < kb) lbytes[i] = rb[k];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxP; k++) {
+        const uint32_t i = k * kMatchThreads + tid;
+        if (i < kp) pdst[i] = rp[k];
+      }
+    }
+    // the new part (a dword that was kept only in part was fetched whole again)
+    {
+      uint32_t *pdst = (uint32_t *)lprev;
+#pragma unroll
+      for (uint32_t k = 0; k < kNewB; k++) {
+        const uint32_t i = kbN + k * kMatchThreads + tid;
+        if (i < nbN) lbytes[i] = nwb[k];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kNewP; k++) {
+        const uint32_t i = kpN + k * kMatchThreads + tid;
+        uint32_t x = nwp[k];
+        x |= (x & 0xFFFFu) ? 0u : 0xFFFFu;  // "no link" becomes 0xFFFF, as in stage()
+        x |= (x >> 16) ? 0u : 0xFFFF0000u;
+        if (i < npN) pdst[i] = x;
+      }
+    }
+    if (tid == 0) s_next = q0;
+    exhausted = false;
+    __syncthreads();
+  }
+  }
 #undef LDH_HOP
 #undef LDH_DEC_MASKED
-#pragma unroll
-  for (int i = 0; i < NW; i++)
-    if (w[i].pend & lane_bit) mout[w[i].q] = w[i].res;
 }
 
 // ------------------------------------------------------------------ k_parse_lazy
