@@ -883,7 +883,7 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   if (tid == 0) s_next = q0;
   __syncthreads();
 
-#ifdef LDH_MATCH_STOP  // profiling builds only: the staging alone
+#if defined(LDH_MATCH_STOP) && LDH_MATCH_STOP == 1  // profiling builds only: the staging alone
   if (lbytes[tid] == 0x12345678u) mout[q0] = lprev[tid];
   return;
 #endif
@@ -1101,6 +1101,9 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
       any |= w[i].act;
     }
     if (!any) break;
+#if defined(LDH_MATCH_STOP) && LDH_MATCH_STOP == 2  // profiling builds only: no drain (results are wrong)
+    break;
+#endif
     steps();
   }
 #pragma unroll

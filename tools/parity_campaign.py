@@ -18,7 +18,10 @@ pool = b"".join(r.tobytes() for r in synth.text_streams(8, 131072)) + T.golden("
 noise = bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
 dct = T.golden("dictionary32768.txt")
 dicts = {n: LD.CreateDictionary(dct[:n], n, T.o_adler32(dct[:n])) for n in (1, 300, 32768)}
-edges = [16384 - 48, 16384 - 47, 16336, 16400, 98304, 98305, 131072 - 48, 131072, 131105, 196608, 229376, 294912, 400000]
+# the narrow / wide boundary (16 KiB), k_seg_links' segments (32768) and runs, k_match_lazy's tiles (20480) and runs of
+# four, k_plan_wave's threshold (17 blocks of 65536)
+edges = [16384 - 48, 16384 - 47, 16336, 16400, 20480, 32768, 40960, 61440, 65536, 81920, 98304, 98305, 131072 - 48, 131072,
+         131105, 163840, 196608, 229376, 262144, 294912, 400000, 1048576, 1114112, 1200000]
 
 
 def piece(n):
@@ -46,6 +49,8 @@ while time.time() - t0 < budget:
     d = dicts.get(dn)
     cnt = int(rng.integers(1, 7))
     lens = [int(rng.choice(edges)) + int(rng.integers(-3, 4)) if rng.random() < 0.5 else int(rng.integers(0, 300000)) for _ in range(cnt)]
+    if level >= 7:
+        lens = [min(x, 300000) for x in lens]  # (the oracle's deep levels are slow on long streams)
     if level == 9:
         lens = [min(x, 60000) for x in lens]  # (the oracle at level 9 is slow)
     cases = [piece(max(0, x)) for x in lens]
