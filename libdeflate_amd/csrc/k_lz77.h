@@ -3,15 +3,20 @@
 // Replaces GetBlockLZ77Result (LD:1241-1484) + LoadStringToTable (LD:1184-1197) and the
 // dictionary chains of CreateDictionary (LD:531-595).
 //
-//   k_sort_links   one workgroup per stream: materialise V = dict ++ input, stable LSD
-//                  radix sort of all positions by their exact trigram (Q1: the "hash" is
-//                  the three bytes themselves), then prevd[v] = distance to the previous
-//                  position with the same trigram (0 = none within 32768).
+//   k_seg_links    levels 4-9, streams beyond 16 KiB: V = dict ++ input in segments of 32768
+//                  positions, each sorted by exact trigram (Q1: the "hash" is the three bytes
+//                  themselves) entirely inside LDS; prevd[v] = distance to the previous position
+//                  with the same trigram (0 = none within 32768), across segments by look-up in
+//                  the previous segment's last-occurrence list.
+//   k_sort_links   the same for short streams (one workgroup per stream, sort through memory);
+//                  for levels 1-3 the sorted array itself and its inverse; V alone for level 0.
 //   k_match_lazy   levels 4-9.  Every position is inserted (Q4) and depth is always
 //                  max_chain (Q3), so the best match at a position does not depend on
-//                  the parse: one lane per position, window bytes + links staged in LDS.
-//   k_parse_lazy   the lazy state machine of LD:1318-1476 (Q5), one lane per deflate block.
-//   k_lz_greedy    levels 1-3: insertion depends on the parse (Q4), one lane per stream.
+//                  the parse: one lane per position, window bytes + links staged in LDS and
+//                  kept there from one tile of a stream to the next.
+//   k_parse_lazy   the lazy state machine of LD:1318-1476 (Q5) as a successor function: one
+//                  workgroup per deflate block, the walk found by relaxation over chunks.
+//   k_lz_greedy    levels 1-3: insertion depends on the parse (Q4), one wavefront per stream.
 #pragma once
 #include "ldh_common.h"
 
