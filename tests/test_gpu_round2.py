@@ -230,6 +230,28 @@ def test_block_plan_of_long_streams(LD, B):
     assert [x for x, _ in back] == streams
 
 
+def test_whole_stream_runs_in_a_big_batch(B):
+    # with 1024 streams or more a workgroup of k_seg_links takes a whole stream (here 10 segments, no segment sorted
+    # twice) and one of k_match_lazy all its tiles (15, the window kept in LDS between them); smaller batches cut
+    # streams into runs of four (covered by the other tests).  1100 streams of unequal length: three compared with the
+    # oracle byte for byte, all round-tripped
+    from libdeflate_amd import synth
+    base = b"".join(r.tobytes() for r in synth.text_streams(6, 131072))
+    rng = np.random.default_rng(5)
+    streams = []
+    for i in range(1100):
+        n = 300000 - int(rng.integers(0, 70000))
+        o = int(rng.integers(0, len(base) - n))
+        streams.append(base[o:o + n])
+    streams[7] = streams[7][:32768 * 9]       # ends on a segment edge
+    streams[8] = streams[8][:20480 * 11 + 1]  # one position into a tile
+    got = B.compress_batch(streams, level=5)
+    for i in (0, 7, 8, 1099):
+        assert got[i] == o_compress(streams[i], level=5), (i, len(streams[i]))
+    back = B.decompress_batch([c for c, _ in got], max_out=300000)
+    assert [x for x, _ in back] == streams
+
+
 def test_pool_of_two_contexts_on_device_0(LD, B):
     # one library, many GPUs.  The box has one GPU, so the pool is two contexts on device 0:
     # the host-pointer batch calls split their streams by bytes over both (two host threads, two sets of streams and
