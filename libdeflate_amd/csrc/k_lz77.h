@@ -790,17 +790,25 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
 
 // ------------------------------------------------------------------ k_match_lazy
 #ifndef LDH_MATCH_TILE
-#define LDH_MATCH_TILE 20480
+#define LDH_MATCH_TILE 16384
 #endif
 #ifndef LDH_MATCH_THREADS
 #define LDH_MATCH_THREADS 1024
 #endif
-constexpr uint32_t kTile = LDH_MATCH_TILE;  // a multiple of 4096, at most 20480 (LDS; one deflate-block end per tile)
+#ifndef LDH_MATCH_MARGIN
+#define LDH_MATCH_MARGIN 4096
+#endif
+// kTile + kMatchMargin: a multiple of 4096, at most 20480 (LDS); a tile holds one deflate-block end at most.
+// kMatchMargin: positions kept in LDS below the window of a tile's first position, so that the walks of the last
+// kMatchMargin positions of the tile before it can go on across the change of tiles instead of being waited for.
+constexpr uint32_t kTile = LDH_MATCH_TILE;
+constexpr uint32_t kMatchMargin = LDH_MATCH_MARGIN;
 constexpr int kMatchThreads = LDH_MATCH_THREADS;
 constexpr int kMatchThreadsNarrow = 256;
 constexpr uint32_t kMatchNarrowMaxV = 16384;  // dictionary + stream up to this long: the narrow version, LDS sized to the batch
-constexpr uint32_t kLdsByteCap = kWindow + kTile + 288;  // window + tile + max match + slack
-constexpr uint32_t kLdsPrevCap = kWindow + kTile + 8;
+constexpr uint32_t kLdsByteCap = kWindow + kMatchMargin + kTile + 288;  // window + margin + tile + max match + slack
+constexpr uint32_t kLdsPrevCap = kWindow + kMatchMargin + kTile + 8;
+static_assert(kLdsByteCap + 2 * kLdsPrevCap <= 160 * 1024 - 64, "k_match_lazy's LDS");
 constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
 #ifndef LDH_MATCH_STEPS
 #define LDH_MATCH_STEPS 8
@@ -877,7 +885,7 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     q1 = (q0 + kTile < n) ? q0 + kTile : n;
     v0 = q0 + D;
     v1 = q1 + D;
-    wbase = (v0 > kWindow ? v0 - kWindow : 0) & ~3u;
+    wbase = (v0 > kWindow + kMatchMargin ? v0 - kWindow - kMatchMargin : 0) & ~3u;
     // a tile (at most 20480 positions) straddles at most one deflate-block end (they are 32768 apart)
     const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
     be_lo = block_end(blk0, n);
@@ -1076,11 +1084,12 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   // (the next tile's new bytes and links are fetched into registers now and arrive while the walks in flight drain)
   constexpr uint32_t kNewB = (kTile / 4 + THREADS - 1) / THREADS + 1, kNewP = (kTile / 2 + THREADS - 1) / THREADS + 1;
   uint32_t nwb[kNewB], nwp[kNewP];
-  uint32_t kbN = 0, kpN = 0, nbN = 0, npN = 0;
+  uint32_t kbN = 0, kpN = 0, nbN = 0, npN = 0, wbn = 0;
   const bool more = THREADS >= 1024 && tile + 1 < tile_first + tiles_per_wg && (tile + 1) * kTile < n;
   if (more) {
     const uint32_t q0n = (tile + 1) * kTile, q1n = (q0n + kTile < n) ? q0n + kTile : n;
-    const uint32_t v0n = q0n + D, v1n = q1n + D, wbn = (v0n > kWindow ? v0n - kWindow : 0) & ~3u;
+    const uint32_t v0n = q0n + D, v1n = q1n + D;
+    wbn = (v0n > kWindow + kMatchMargin ? v0n - kWindow - kMatchMargin : 0) & ~3u;
     kbN = (v1 + 280 - wbn) / 4;  // whole dwords of the bytes / links that stay (v1 = v0n)
     kpN = (v1 - wbn) / 2;
     nbN = (v1n + 280 - wbn + 3) / 4;
@@ -1098,12 +1107,18 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
       nwp[k] = i < npN ? psrc[i] : 0u;
     }
   }
+  // The walks in flight drain -- at the run's last tile all of them; before another tile only those whose window
+  // reaches below what LDS will hold then (positions more than kMatchMargin before the tile's end: rare).  The
+  // others go on across the change of tiles, their LDS offsets moved along with the data (waiting for every walk
+  // at every tile's end was 0.7 of the kernel's 20.7 ms per GiB).
+  const uint32_t sh = more ? wbn - wbase : 0u;           // positions the window moves on: a multiple of 4
+  const uint32_t must_end_below = sh ? sh + kWindow : 0u;  // walks at LDS offsets below this one
   for (;;) {
     unsigned long long any = 0;
 #pragma unroll
     for (int i = 0; i < NW; i++) {
       compare(w[i]);
-      any |= w[i].act;
+      any |= more ? (w[i].act & ballot64(w[i].vb < must_end_below)) : w[i].act;
     }
     if (!any) break;
 #if defined(LDH_MATCH_STOP) && LDH_MATCH_STOP == 2  // profiling builds only: no drain (results are wrong)
@@ -1111,26 +1126,29 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
 #endif
     steps();
   }
+  if (!more) {
 #pragma unroll
-  for (int i = 0; i < NW; i++) {
-    if (w[i].pend & lane_bit) mout[w[i].q] = w[i].res;
-    w[i].pend = 0;
-    w[i].pm = 0;
-    if (HAS_DICT) w[i].seed = 0;
+    for (int i = 0; i < NW; i++)
+      if (w[i].pend & lane_bit) mout[w[i].q] = w[i].res;
+    break;
   }
-  // ---- the next tile of the run
-  if (!more) break;
+  // ---- the next tile of the run (a lane that is done keeps its result until its next refill, as within a tile)
   tile++;
   {
-    const uint32_t wb_old = wbase, v1_old = v1;
-    __syncthreads();  // every walk of the tile has ended
+    const uint32_t v1_old = v1;
+    __syncthreads();  // no walk reads LDS now
     set_tile(tile * kTile);
-    const uint32_t sh = wbase - wb_old;  // positions the window moves on: a multiple of 4
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      w[i].vb -= sh;
+      w[i].cb -= sh;
+      w[i].lo -= (int32_t)sh;
+    }
     // what stays: bytes [wbase, v1_old + 280) and links [wbase, v1_old), through registers (the ranges overlap)
     const uint32_t kb = (v1_old + 280 - wbase) / 4, kp = (v1_old - wbase) / 2;  // whole dwords kept
     if (sh) {
-      constexpr uint32_t kMaxB = (kWindow + 288 + 4 * THREADS - 1) / (4 * THREADS) + 1;
-      constexpr uint32_t kMaxP = (kWindow + 2 * THREADS - 1) / (2 * THREADS) + 1;
+      constexpr uint32_t kMaxB = (kWindow + kMatchMargin + 288 + 4 * THREADS - 1) / (4 * THREADS) + 1;
+      constexpr uint32_t kMaxP = (kWindow + kMatchMargin + 2 * THREADS - 1) / (2 * THREADS) + 1;
       uint32_t rb[kMaxB], rp[kMaxP];
       uint32_t *pdst = (uint32_t *)lprev;
 #pragma unroll
