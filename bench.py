@@ -121,12 +121,24 @@ def main():
                          "empty steps and print the line with value null; no GPU work")
     args = ap.parse_args()
 
-    from libdeflate_amd import shard
+    # shard.py is loaded by path: importing the package would dlopen the HIP runtime and libdeflate_hip.so, and the
+    # launcher below must stay a process that has loaded nothing of the GPU stack
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ldh_shard", os.path.join(ROOT, "libdeflate_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
     rank, local_rank, world = shard.env_world()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N`: this process becomes the launcher of N rank processes (one per GPU).  It has
-        # made no GPU call (torch is not even imported yet) and makes none: it waits and hands on the exit code.
-        sys.exit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        # made no GPU call (neither torch nor the library is loaded) and makes none: it waits, stops the other ranks
+        # when one fails, and hands on the exit code.  Under a profiler the profiler's preloaded library has already
+        # initialised the GPU in this process, and starting children from it is the launcher hop this pool forbids.
+        preload = os.environ.get("LD_PRELOAD", "")
+        if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in preload:
+            sys.exit("bench.py: --gpus %d under a profiler: profile ONE rank instead (python bench.py --gpus 1, or "
+                     "set RANK/LOCAL_RANK/WORLD_SIZE=1 yourself)" % args.gpus)
+        sys.exit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                    timeout=float(os.environ.get("LDH_LAUNCH_TIMEOUT", "3000"))))
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if args.rendezvous_only:
@@ -209,6 +221,16 @@ def main():
             t_c = sum(v[0] for k, v in pr.items() if k != "k_inflate")
             t_d = sum(v[0] for k, v in pr.items() if k == "k_inflate")
             good = bool(torch.equal(back, data)) and int(status.abs().sum()) == 0
+            if rank == 0:  # and, like the headline, four streams' bytes against the oracle (a valid but different
+                # parse would pass the round trip)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import ldtest as T
+                lens4 = comp_len[:4].cpu().numpy()
+                cbuf4 = comp[: 4 * stride].cpu().numpy()
+                rows4 = data[: 4 * L].view(4, L).cpu().numpy()
+                for i in range(4):
+                    want, _ = T.o_compress(rows4[i].tobytes(), level=lv)
+                    good = good and cbuf4[i * stride: i * stride + int(lens4[i])].tobytes() == want
             other[str(lv)] = {"compress_GBps": S * L / 1e6 / max(t_c, 1e-9), "decompress_GBps": S * L / 1e6 / max(t_d, 1e-9),
                               "roundtrip_GBps": S * L / 1e6 / max(t_c + t_d, 1e-9),
                               "compress_ratio": S * L / max(int(comp_len.sum().item()), 1), "verified": good}

@@ -50,13 +50,18 @@ extern "C" {
 typedef struct ldh_dict ldh_dict;
 
 /* ---- lifecycle ------------------------------------------------------------- */
-int ldh_init(int device); /* one context (streams + workspace) on this HIP device; idempotent for the same device */
+/* One context (streams + workspace) on this HIP device; idempotent for the same device.  After ldh_init_devices()
+ * it selects the pool's first context on `device` as the default one; a device that has no context yet while a
+ * default exists gives LDH_E_ARG (device out of range: LDH_E_ARG; a failing HIP call: LDH_E_HIP). */
+int ldh_init(int device);
 void ldh_shutdown(void);
 int ldh_device_count(void);
 const char *ldh_last_error(void);
 void *ldh_stream(void); /* hipStream_t the *_dev calls enqueue on (current context) */
 /* Waits for the current context's stream.  LDH_E_TOO_LONG if a *_dev compress call since the last
- * ldh_sync met streams longer than its max_in_len: those have out_len 0 (they are never truncated). */
+ * ldh_sync met streams longer than its max_in_len: those have out_len 0 (they are never truncated).  The counter is
+ * read and cleared on the library stream itself.  Callers that wait some other way (hipStreamSynchronize(ldh_stream()),
+ * an event) never see this code: for them out_len[s] == 0 is the per-stream signal (no input compresses to 0 bytes). */
 int ldh_sync(void);
 
 /* ---- one library, many GPUs (host-side scatter, no inter-GPU collective) --------------
@@ -128,14 +133,17 @@ int ldh_decompress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size
                              int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
                              uint32_t *d_out_len, uint32_t *d_bytes_left, int32_t *d_status);
 
-/* ldh_decompress_batch_dev for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results;
+/* ldh_decompress_batch_dev for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc,
+ * code that runs beside a HIP graph capture).  No counterpart in the reference.  Same arguments and results;
  * it calls no hipMalloc / hipFree: the per-stream scratch of the zlib trailer check lives in static device
  * memory (8 bytes x LDH_NOALLOC_MAX_STREAMS per GPU, held until the process ends).  count above
  * LDH_NOALLOC_MAX_STREAMS gives LDH_E_CAPACITY; a dictionary must already be resident on the device
  * (it is after ldh_dict_create on this context or any earlier call with it), else LDH_E_ARG.  Profiling is
- * off for the call.  Calls on one GPU share the scratch: do not overlap them (the library's stream and
- * context lock order calls made through one context). */
+ * off for the call.  The work is enqueued on the library's own stream (ldh_stream()), like every *_dev call: it is
+ * NOT captured into a graph the caller is recording on another stream; and the first launch of a kernel on a device
+ * may still load its code object, so run one call of each format once at start-up.  Calls on one GPU share the
+ * scratch: calls made through one context are ordered by its stream; a call made through another context of the
+ * same GPU (ldh_init_devices with a device listed twice) is made to wait for the previous one by an event. */
 #define LDH_NOALLOC_MAX_STREAMS 65536
 int ldh_decompress_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off, size_t count,
                                      int fmt, const ldh_dict *dict, uint8_t *d_out, size_t out_stride,
@@ -205,6 +213,9 @@ int ldh_timer_stop(double *ms);
  * host memory.  what: 0 prev-link deltas (uint16 per virtual position), 1 per-position
  * best match (uint32: len<<16|dist), 2 tokens (uint32), 3 block table (opaque bytes). */
 int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes);
+/* Device, pinned-host and event allocations the library has made since it was loaded (hipMalloc, hipHostMalloc,
+ * hipEventCreate calls): a test can show that an entry point allocated nothing by reading it before and after. */
+uint64_t ldh_debug_alloc_count(void);
 
 #ifdef __cplusplus
 }

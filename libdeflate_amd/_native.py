@@ -89,6 +89,7 @@ _SIGS = {
     "ldh_timer_start": (C.c_int, []),
     "ldh_timer_stop": (C.c_int, [C.POINTER(C.c_double)]),
     "ldh_debug_fetch": (C.c_int, [C.c_int, sz, C.c_void_p, sz, C.POINTER(sz)]),
+    "ldh_debug_alloc_count": (C.c_uint64, []),
 }
 
 EXPORTS = sorted(_SIGS)

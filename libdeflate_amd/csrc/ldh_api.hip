@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,7 @@ static __device__ __align__(256) uint32_t scratch[2 * kNoAllocMaxStreams];
 namespace {
 
 thread_local std::string g_err;
+std::atomic<uint64_t> g_allocs{0};  // hipMalloc / hipHostMalloc calls the library has made (ldh_debug_alloc_count)
 
 struct DevBuf {
   void *p = nullptr;
@@ -89,7 +91,9 @@ struct Ctx {
   DevBuf h_in, h_off, h_out, h_len, h_aux8, h_aux32a, h_aux32b, codec_tmp;
   Slot slot[3];
   uint32_t *flags = nullptr;    // [0] streams longer than max_in_len since the last ldh_sync (k_plan)
+  uint32_t *flags_host = nullptr;  // pinned word ldh_sync reads flags[0] into, on cx.stream
   uint32_t *noalloc = nullptr;  // this device's copy of `scratch`
+  hipEvent_t ev_noalloc = nullptr;  // end of this context's last ldh_decompress_batch_dev_noalloc (see g_scratch_last)
   bool attr_done = false;
   // last compress batch (for ldh_debug_fetch)
   Batch last{};
@@ -106,6 +110,11 @@ std::mutex g_mu;                 // guards the context tables below
 Ctx *g_default = nullptr;        // the context of ldh_init(device): what every call without a pool uses
 std::vector<Ctx *> g_pool;       // ldh_init_devices(): contexts the host-pointer batch calls are split over
 thread_local Ctx *t_cur = nullptr;  // ldh_use_context(): this thread's choice among the pool
+// `scratch` is one array per GPU, but a GPU may carry several contexts (ldh_init_devices({0, 0})), each with a stream of
+// its own: per device, the context whose no-allocation call used the array last and the event that marks its end.  The
+// next such call from another context makes its stream wait for that event first (no allocation, no host wait).
+std::mutex g_scratch_mu;
+std::vector<std::pair<int, Ctx *>> g_scratch_last;  // (device, context)
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -141,6 +150,7 @@ int ensure(DevBuf &b, size_t bytes) {
     b.cap = 0;
   }
   size_t want = bytes + bytes / 8 + 4096;
+  g_allocs++;
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     want = bytes + 4096;
@@ -158,6 +168,7 @@ hipEvent_t get_event(Ctx &cx) {
     return e;
   }
   hipEvent_t e;
+  g_allocs++;
   hipEventCreate(&e);
   return e;
 }
@@ -225,6 +236,7 @@ const uint8_t *dict_on(Ctx &cx, const ldh_dict *dc) {
     if (e.first == cx.device) return e.second;
   uint8_t *p = nullptr;
   const size_t n = d->bytes.size();
+  g_allocs++;
   if (hipMalloc((void **)&p, n + 64) != hipSuccess) return nullptr;
   if (hipMemset(p, 0, n + 64) != hipSuccess || hipMemcpy(p, d->bytes.data(), n, hipMemcpyHostToDevice) != hipSuccess) {
     hipFree(p);
@@ -239,6 +251,7 @@ const ldh::CodecTables *codec_on(Ctx &cx, const ldh_codec *cc) {
   for (auto &e : c->dev)
     if (e.first == cx.device) return e.second;
   ldh::CodecTables *p = nullptr;
+  g_allocs++;
   if (hipMalloc((void **)&p, c->img.size()) != hipSuccess) return nullptr;
   if (hipMemcpy(p, c->img.data(), c->img.size(), hipMemcpyHostToDevice) != hipSuccess) {
     hipFree(p);
@@ -500,6 +513,7 @@ int ensure_pinned(PinBuf &b, size_t bytes) {
     b.cap = 0;
   }
   const size_t want = bytes + bytes / 8 + 4096;
+  g_allocs++;
   const hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
   if (e != hipSuccess) return fail(LDH_E_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
   b.cap = want;
@@ -588,15 +602,18 @@ void par_memcpy(void *dst, const void *src, size_t bytes) {
 extern "C" {
 
 namespace {
-Ctx *ctx_create(int device) {  // g_mu held
+void ctx_destroy(Ctx *c);
+// g_mu held.  Returns the context, or nullptr with *rc = the error code (g_err holds the message); whatever a failed
+// creation had made so far is released again.
+Ctx *ctx_create(int device, int *rc) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
-    fail(LDH_E_HIP, "no HIP device: %s", hipGetErrorString(e));
+    *rc = fail(LDH_E_HIP, "no HIP device: %s", hipGetErrorString(e));
     return nullptr;
   }
   if (device < 0 || device >= n) {
-    fail(LDH_E_ARG, "device %d out of range (count %d)", device, n);
+    *rc = fail(LDH_E_ARG, "device %d out of range (count %d)", device, n);
     return nullptr;
   }
   Ctx *c = new Ctx;
@@ -604,21 +621,32 @@ Ctx *ctx_create(int device) {  // g_mu held
   void *sym = nullptr;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_noalloc, hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc((void **)&c->flags, 256)) != hipSuccess || (e = hipMemset(c->flags, 0, 256)) != hipSuccess ||
+      (e = hipHostMalloc((void **)&c->flags_host, 64, hipHostMallocDefault)) != hipSuccess ||
       // this GPU's copy of the no-allocation scratch: its address here, never the array's name, is what kernels get
       (e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch))) != hipSuccess) {
-    fail(LDH_E_HIP, "context on device %d: %s", device, hipGetErrorString(e));
+    *rc = fail(LDH_E_HIP, "context on device %d: %s", device, hipGetErrorString(e));
+    ctx_destroy(c);
     delete c;
     return nullptr;
   }
   c->noalloc = (uint32_t *)sym;
+  {
+    std::lock_guard<std::mutex> sl(g_scratch_mu);
+    g_scratch_last.reserve(64);
+    bool have = false;
+    for (auto &en : g_scratch_last) have = have || en.first == device;
+    if (!have) g_scratch_last.push_back({device, nullptr});
+  }
+  *rc = 0;
   return c;
 }
 void ctx_destroy(Ctx *c) {
   if (!c) return;
   std::lock_guard<std::mutex> lk(c->mu);
   hipSetDevice(c->device);
-  hipDeviceSynchronize();
+  if (c->stream) hipDeviceSynchronize();
   Ctx &cx = *c;
   pipeline_free(cx);
   for (DevBuf *b : {&cx.vbuf, &cx.prevd, &cx.bufA, &cx.bufB, &cx.bufC, &cx.blocks, &cx.adler, &cx.misc32a, &cx.misc32b, &cx.h_in,
@@ -632,26 +660,38 @@ void ctx_destroy(Ctx *c) {
     hipEventDestroy(p.b);
   }
   for (hipEvent_t e : cx.event_pool) hipEventDestroy(e);
+  cx.pending.clear();
+  cx.event_pool.clear();
+  {
+    std::lock_guard<std::mutex> sl(g_scratch_mu);
+    for (auto &e : g_scratch_last)
+      if (e.second == c) e.second = nullptr;
+  }
   if (cx.flags) hipFree(cx.flags);
-  hipEventDestroy(cx.t0);
-  hipEventDestroy(cx.t1);
-  hipStreamDestroy(cx.stream);
+  if (cx.flags_host) hipHostFree(cx.flags_host);
+  if (cx.ev_noalloc) hipEventDestroy(cx.ev_noalloc);
+  if (cx.t0) hipEventDestroy(cx.t0);
+  if (cx.t1) hipEventDestroy(cx.t1);
+  if (cx.stream) hipStreamDestroy(cx.stream);
+  cx.flags = cx.flags_host = nullptr;
+  cx.ev_noalloc = cx.t0 = cx.t1 = nullptr;
+  cx.stream = nullptr;
 }
 }  // namespace
 
 int ldh_init(int device) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_default) {
-    if (g_default->device == device) return 0;
-    return fail(LDH_E_ARG, "already initialised on device %d (ldh_init_devices() drives several)", g_default->device);
-  }
-  for (Ctx *c : g_pool)  // ldh_init_devices() came first: its first context on this device is the default
+  if (g_default && g_default->device == device) return 0;
+  for (Ctx *c : g_pool)  // a pool exists (ldh_init_devices): its first context on this device becomes the default
     if (c->device == device) {
       g_default = c;
       return 0;
     }
-  Ctx *c = ctx_create(device);
-  if (!c) return LDH_E_HIP;
+  if (g_default)
+    return fail(LDH_E_ARG, "already initialised on device %d (ldh_init_devices() drives several)", g_default->device);
+  int rc = 0;
+  Ctx *c = ctx_create(device, &rc);
+  if (!c) return rc;
   g_default = c;
   return 0;
 }
@@ -675,14 +715,17 @@ int ldh_init_devices(const int *devices, int n) {
       c = g_default;
       default_used = true;
     } else {
-      c = ctx_create(d);
+      int rc = 0;
+      c = ctx_create(d, &rc);
       if (!c) {
+        const std::string msg = g_err;  // (ctx_destroy below makes HIP calls of its own)
         for (Ctx *m : made)
           if (m != g_default) {
             ctx_destroy(m);
             delete m;
           }
-        return LDH_E_HIP;
+        g_err = msg;
+        return rc;
       }
     }
     made.push_back(c);
@@ -738,12 +781,14 @@ void *ldh_stream(void) {
 }
 int ldh_sync(void) {
   CTX_ENTER(cx);
+  // streams a *_dev compress call found longer than its max_in_len (k_plan counts them; their out_len is 0).  The
+  // counter is read and cleared ON the library stream (the stream is non-blocking: a null-stream memset would not be
+  // ordered against a compress call enqueued right after this one returns, and could wipe out its report)
+  HIPCHK(hipMemcpyAsync(cx.flags_host, cx.flags, 4, hipMemcpyDeviceToHost, cx.stream));
   HIPCHK(hipStreamSynchronize(cx.stream));
-  // streams a *_dev compress call found longer than its max_in_len (k_plan counts them; their out_len is 0)
-  uint32_t too_long = 0;
-  HIPCHK(hipMemcpy(&too_long, cx.flags, 4, hipMemcpyDeviceToHost));
+  const uint32_t too_long = *(volatile uint32_t *)cx.flags_host;
   if (too_long) {
-    HIPCHK(hipMemset(cx.flags, 0, 4));
+    HIPCHK(hipMemsetAsync(cx.flags, 0, 4, cx.stream));
     return fail(LDH_E_TOO_LONG, "%u stream(s) longer than max_in_len were not compressed (out_len 0)", too_long);
   }
   return 0;
@@ -881,8 +926,30 @@ int ldh_decompress_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_o
   }
   const bool prof = cx.prof;  // (profiling brackets launches with events from a pool that may have to grow)
   cx.prof = false;
-  const int rc = decompress_dev_locked(cx, d_in, d_in_off, nullptr, 0, count, fmt, dict, d_out, out_stride, d_out_len,
-                                       d_bytes_left, d_status, cx.noalloc);
+  int rc = 0;
+  {
+    // the device's one scratch array: behind the last no-allocation call another context made on this GPU
+    std::lock_guard<std::mutex> sl(g_scratch_mu);
+    std::pair<int, Ctx *> *slot = nullptr;
+    for (auto &e : g_scratch_last)
+      if (e.first == cx.device) slot = &e;
+    if (!slot) {  // (first such call on this device: one table entry per GPU, reserved at start-up below)
+      g_scratch_last.push_back({cx.device, nullptr});
+      slot = &g_scratch_last.back();
+    }
+    if (slot->second && slot->second != &cx) {
+      const hipError_t e = hipStreamWaitEvent(cx.stream, slot->second->ev_noalloc, 0);
+      if (e != hipSuccess) rc = fail(LDH_E_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+    }
+    if (!rc)
+      rc = decompress_dev_locked(cx, d_in, d_in_off, nullptr, 0, count, fmt, dict, d_out, out_stride, d_out_len,
+                                 d_bytes_left, d_status, cx.noalloc);
+    if (!rc) {
+      const hipError_t e = hipEventRecord(cx.ev_noalloc, cx.stream);
+      if (e != hipSuccess) rc = fail(LDH_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+      slot->second = &cx;
+    }
+  }
   cx.prof = prof;
   return rc;
 }
@@ -1575,6 +1642,7 @@ int ldh_timer_stop(double *ms) {
 }
 
 // ---- inspection ---------------------------------------------------------------------
+uint64_t ldh_debug_alloc_count(void) { return g_allocs.load(); }
 int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes) {
   CTX_ENTER(cx);
   if (!cx.have_last || stream >= cx.last.count) return fail(LDH_E_ARG, "no such stream in the last batch");

@@ -26,7 +26,10 @@ def init(backend, device=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    kw = {}
+    import datetime
+    # (a rank that never arrives must not hold the others for the default half hour: launch_ranks stops its siblings
+    # at once, this bounds the same case under torch.distributed.run)
+    kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("LDH_DIST_TIMEOUT", "600")))}
     if device is not None and backend == "nccl":
         kw["device_id"] = device
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
@@ -81,26 +84,59 @@ def total(value, dist=None, torch=None, device="cpu"):
     return _reduce(dist, torch, value, torch.float64, dist.ReduceOp.SUM, device)
 
 
-def launch_ranks(argv, world, env=None):
-    """Start `world` fresh processes of `argv` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
-    torch.distributed.run would) and wait for them.  Returns the first non-zero exit code, else 0.
-    The caller must not have touched the GPU: the children are new processes (no re-exec of this one), and
-    a parent that holds no GPU state just waits."""
+def _free_port():
     with socket.socket() as sk:  # a free rendezvous port on the loopback interface
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+        return sk.getsockname()[1]
+
+
+def launch_ranks(argv, world, env=None, timeout=None, grace=5.0):
+    """Start `world` fresh processes of `argv` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would) and wait for them.  Returns the first non-zero exit code, else 0.
+    The children are polled together: the moment one of them exits non-zero (no device, out of memory, a crash) the
+    others -- which would sit in init_process_group or a barrier until the distributed timeout -- are terminated
+    (SIGTERM, SIGKILL after `grace` seconds) and that rank's code is returned; `timeout` seconds (None: no limit) for
+    the whole job end it the same way with code 124.  The caller must not have touched the GPU: the children are new
+    processes (never a re-exec of this one), and a parent that holds no GPU state just waits."""
+    port = _free_port()
     procs = []
     for r in range(world):
         e = dict(os.environ if env is None else env)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
                   "MASTER_PORT": str(port)})
         procs.append(subprocess.Popen(list(argv), env=e))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + grace
+        for p in procs:
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0 = time.monotonic()
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:
-        for p in procs:  # (all have exited; nothing to kill -- report which rank failed first)
-            if p.returncode:
-                sys.stderr.write("rank process %d exited with %d\n" % (procs.index(p), p.returncode))
+    try:
+        while True:
+            running = 0
+            for r, p in enumerate(procs):
+                code = p.poll()
+                if code is None:
+                    running += 1
+                elif code != 0 and rc == 0:
+                    rc = code
+                    sys.stderr.write("rank process %d exited with %d: stopping the other ranks\n" % (r, code))
+            if rc or not running:
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                rc = 124
+                sys.stderr.write("ranks still running after %.0f s: stopping them\n" % timeout)
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
     return rc

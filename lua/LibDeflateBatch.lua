@@ -9,6 +9,17 @@
   local texts        = Batch.EncodeForPrint(list)
   local datas        = Batch.DecodeForPrint(list)                       -- datas[i] string or nil
 
+  -- caller-owned memory (cdata pointers: malloc'ed, mmap'ed or pinned buffers; nothing goes through Lua strings):
+  local rc = Batch.CompressBuffers(in_ptr, off_ptr, n, fmt, configs, dictionary, out_ptr, out_stride, len_ptr, pad_ptr)
+  local rc = Batch.DecompressBuffers(in_ptr, off_ptr, n, fmt, dictionary, out_ptr, out_stride, len_ptr, left_ptr, status_ptr)
+  local buf  = Batch.Alloc(nbytes)               -- malloc'ed uint8_t*, freed by the garbage collector (ffi.gc)
+  local need = Batch.CompressBound(maxlen)       -- out_stride for CompressBuffers
+
+The list forms build ONE Lua string (table.concat) and ONE ffi.new array for the results: both live on LuaJIT's
+garbage-collected heap, which a non-GC64 build limits to 1-2 GiB in all.  Use them up to a few hundred MiB per call
+(inputs + count * out_stride); beyond that -- the bench's batch is 1 GiB in and 1.3 GiB of slots -- use the
+*Buffers forms, which hand the caller's pointers straight to ldh_compress_batch / ldh_decompress_batch.
+
 Each call is ONE trip through the C ABI (ldh_*_batch of include/libdeflate_hip.h): one copy in, one set of
 kernel launches over all strings, one copy out -- and, after ldh_init_devices, split over every GPU of the
 node by the library.  The reference has no counterpart (one string per call); argument checks follow
@@ -28,6 +39,10 @@ int ldh_print6_encode_batch(const uint8_t *in_base, const uint64_t *in_off, size
                             size_t out_stride, uint32_t *out_len);
 int ldh_print6_decode_batch(const uint8_t *in_base, const uint64_t *in_off, size_t count, uint8_t *out_base,
                             size_t out_stride, uint32_t *out_len, uint8_t *ok);
+]]
+ffi.cdef [[
+void *malloc(size_t size);
+void free(void *ptr);
 ]]
 
 local Batch = {}
@@ -72,6 +87,60 @@ function Batch.Compress(strings, fmt, configs, dictionary)
   check(C.ldh_compress_batch(data, off, n, fmt or 0, level, strategy, handle_of(dictionary), out, stride, ol, pb))
   for i = 1, n do res[i] = ffi.string(out + (i - 1) * stride, ol[i - 1]); pads[i] = pb[i - 1] end
   return res, pads
+end
+
+-- ---- caller-owned memory ------------------------------------------------------------------------------------
+-- The same two calls over cdata pointers: stream i is in_ptr[off_ptr[i] .. off_ptr[i+1]) (off_ptr: uint64_t[n+1]),
+-- its result goes to out_ptr + i*out_stride with its length in len_ptr[i] (uint32_t[n]).  Nothing is copied through
+-- Lua strings and nothing is allocated on the Lua heap, so a batch may be as large as host memory allows.
+-- Returns the number of streams; results are read from the caller's buffers.
+local function is_ptr(p) return type(p) == "cdata" end
+local function need_ptrs(fname, ...)
+  local names = {...}
+  for i = 1, #names, 2 do
+    if not is_ptr(names[i + 1]) then
+      error(("Usage: LibDeflateBatch.%s: '%s' - cdata pointer expected got '%s'."):format(fname, names[i], type(names[i + 1])), 3)
+    end
+  end
+end
+
+function Batch.CompressBound(maxlen) return tonumber(C.ldh_compress_bound(maxlen)) end
+
+-- nbytes of malloc'ed memory as uint8_t* (outside LuaJIT's heap), released when the cdata is collected
+function Batch.Alloc(nbytes)
+  local p = ffi.C.malloc(nbytes)
+  if p == nil then error("LibDeflateBatch.Alloc: out of memory (" .. tostring(nbytes) .. " bytes)", 2) end
+  return ffi.gc(ffi.cast("uint8_t *", p), ffi.C.free)
+end
+
+-- out_stride: a multiple of 16, at least Batch.CompressBound(longest stream); pad_ptr: uint8_t[n]
+function Batch.CompressBuffers(in_ptr, off_ptr, n, fmt, configs, dictionary, out_ptr, out_stride, len_ptr, pad_ptr)
+  local ok, err = hip.IsValidArguments("", dictionary ~= nil, dictionary, true, configs)
+  if not ok then error("Usage: LibDeflateBatch.CompressBuffers(in_ptr, off_ptr, n, fmt, configs, dictionary, out_ptr, out_stride, len_ptr, pad_ptr): " .. err, 2) end
+  need_ptrs("CompressBuffers", "in_ptr", in_ptr, "off_ptr", off_ptr, "out_ptr", out_ptr, "len_ptr", len_ptr, "pad_ptr", pad_ptr)
+  local level, strategy = -1, 0
+  if configs then level = configs.level or -1; strategy = hip.STRATEGY[configs.strategy] or 0 end
+  if n == 0 then return 0 end
+  check(C.ldh_compress_batch(ffi.cast("const uint8_t *", in_ptr), ffi.cast("const uint64_t *", off_ptr), n, fmt or 0, level,
+                             strategy, handle_of(dictionary), ffi.cast("uint8_t *", out_ptr), out_stride,
+                             ffi.cast("uint32_t *", len_ptr), ffi.cast("uint8_t *", pad_ptr)))
+  return n
+end
+
+-- left_ptr: uint32_t[n] (unprocessed input bytes where status is 0), status_ptr: int32_t[n] (0, LibDeflate's codes
+-- 2 / -1..-17, or 1 = the slot of out_stride bytes was too small)
+function Batch.DecompressBuffers(in_ptr, off_ptr, n, fmt, dictionary, out_ptr, out_stride, len_ptr, left_ptr, status_ptr)
+  if dictionary ~= nil then
+    local ok, err = hip.IsValidArguments("", true, dictionary)
+    if not ok then error("Usage: LibDeflateBatch.DecompressBuffers(in_ptr, off_ptr, n, fmt, dictionary, out_ptr, out_stride, len_ptr, left_ptr, status_ptr): " .. err, 2) end
+  end
+  need_ptrs("DecompressBuffers", "in_ptr", in_ptr, "off_ptr", off_ptr, "out_ptr", out_ptr, "len_ptr", len_ptr, "left_ptr", left_ptr,
+            "status_ptr", status_ptr)
+  if n == 0 then return 0 end
+  check(C.ldh_decompress_batch(ffi.cast("const uint8_t *", in_ptr), ffi.cast("const uint64_t *", off_ptr), n, fmt or 0,
+                               handle_of(dictionary), ffi.cast("uint8_t *", out_ptr), out_stride, ffi.cast("uint32_t *", len_ptr),
+                               ffi.cast("uint32_t *", left_ptr), ffi.cast("int32_t *", status_ptr)))
+  return n
 end
 
 -- max_out (optional): a hard limit on one result's size; without it slots grow (x4) until every stream fits,

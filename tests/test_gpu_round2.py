@@ -244,9 +244,12 @@ def test_whole_stream_runs_in_a_big_batch(B):
         o = int(rng.integers(0, len(base) - n))
         streams.append(base[o:o + n])
     streams[7] = streams[7][:32768 * 9]       # ends on a segment edge
-    streams[8] = streams[8][:20480 * 11 + 1]  # one position into a tile
+    streams[8] = streams[8][:16384 * 11 + 1]  # one position into a tile (tiles are 16384 positions since round 2)
+    streams[9] = streams[9][:20480 * 11 + 1]  # (the round-1 tile size, kept as a case)
     got = B.compress_batch(streams, level=5)
-    for i in (0, 7, 8, 1099):
+    # (the host-pointer entry point cuts this batch into 64 MiB pieces of some 250 streams, so this test covers runs
+    # of four segments / tiles behind the piece pipeline; the whole-stream mode itself is tests/test_gpu_round3.py)
+    for i in (0, 7, 8, 9, 1099):
         assert got[i] == o_compress(streams[i], level=5), (i, len(streams[i]))
     back = B.decompress_batch([c for c, _ in got], max_out=300000)
     assert [x for x, _ in back] == streams

@@ -15,7 +15,7 @@ def _device_batch(torch, comp):
     return data, torch.tensor(off, dtype=torch.int64).cuda()
 
 
-def _run(N, torch, fn, comp, fmt, dict_handle, cap):
+def _run(N, torch, fn, comp, fmt, dict_handle, cap, no_alloc=False):
     data, off = _device_batch(torch, comp)
     n = len(comp)
     out = torch.full((n * cap,), 0xEE, dtype=torch.uint8, device="cuda")
@@ -23,9 +23,15 @@ def _run(N, torch, fn, comp, fmt, dict_handle, cap):
     left = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     status = torch.full((n,), 99, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
+    allocs, free = N.lib.ldh_debug_alloc_count(), torch.cuda.mem_get_info()[0]
     N.check(fn(data.data_ptr(), off.data_ptr(), n, fmt, dict_handle, out.data_ptr(), cap, out_len.data_ptr(),
                left.data_ptr(), status.data_ptr()))
     N.check(N.lib.ldh_sync())
+    if no_alloc:
+        # show that nothing was allocated, not only that the results agree: the library's own count of
+        # hipMalloc / hipHostMalloc / hipEventCreate calls, and the device's free memory as the driver reports it
+        assert N.lib.ldh_debug_alloc_count() == allocs
+        assert torch.cuda.mem_get_info()[0] == free
     ol, st = out_len.cpu().numpy(), status.cpu().numpy()
     rows = out.cpu().numpy().reshape(n, cap)
     return [(rows[i, : ol[i]].tobytes() if st[i] == 0 else None, int(st[i]), int(left[i])) for i in range(n)]
@@ -48,7 +54,7 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
             comp[4] = comp[4][: len(comp[4]) // 2]
             h = d.handle() if use_dict else None
             want = _run(N, torch, N.lib.ldh_decompress_batch_dev, comp, fmt, h, cap)
-            got = _run(N, torch, N.lib.ldh_decompress_batch_dev_noalloc, comp, fmt, h, cap)
+            got = _run(N, torch, N.lib.ldh_decompress_batch_dev_noalloc, comp, fmt, h, cap, no_alloc=True)
             assert got == want, (fmt, use_dict, len(streams))
             assert [g[0] for i, g in enumerate(got) if i not in (2, 4)] == [s for i, s in enumerate(streams) if i not in (2, 4)]
     # beyond the static scratch: a clear error, no partial work

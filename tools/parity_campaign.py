@@ -2,7 +2,9 @@
 """One-off randomized parity campaign on the GPU (a wider net than tests/: not collected by pytest): random
 batch shapes around the sort's narrow / wide / segmented thresholds, all lazy levels, with and without a
 dictionary, raw and zlib, compared byte for byte with the oracle and round-tripped on the device.
-usage: python tools/parity_campaign.py [seconds]"""
+usage: python tools/parity_campaign.py [seconds] [big]
+`big`: every batch is padded to 1024..1100 streams and goes through ONE ldh_compress_batch_dev call, so that the
+whole-stream runs of k_seg_links / k_match_lazy (what the bench and BASELINE configs[2] run) are what is compared."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,13 +15,14 @@ from libdeflate_amd import LibDeflate as LD, batch as B, synth, _native as N
 
 N.init(0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+BIG = len(sys.argv) > 2 and sys.argv[2] == "big"
 rng = np.random.default_rng(20261110)
 pool = b"".join(r.tobytes() for r in synth.text_streams(8, 131072)) + T.golden("totalrp3.txt") + T.golden("encode_6bit_weakaura.txt")
 noise = bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
 dct = T.golden("dictionary32768.txt")
 dicts = {n: LD.CreateDictionary(dct[:n], n, T.o_adler32(dct[:n])) for n in (1, 300, 32768)}
-# the narrow / wide boundary (16 KiB), k_seg_links' segments (32768) and runs, k_match_lazy's tiles (20480) and runs of
-# four, k_plan_wave's threshold (17 blocks of 65536)
+# the narrow / wide boundary (16 KiB), k_seg_links' segments (32768) and runs, k_match_lazy's tiles (16384 + a margin
+# of 4096; 20480 in round 1) and runs of four, k_plan_wave's threshold (17 blocks of 65536)
 edges = [16384 - 48, 16384 - 47, 16336, 16400, 20480, 32768, 40960, 61440, 65536, 81920, 98304, 98305, 131072 - 48, 131072,
          131105, 163840, 196608, 229376, 262144, 294912, 400000, 1048576, 1114112, 1200000]
 
@@ -54,6 +57,22 @@ while time.time() - t0 < budget:
     if level == 9:
         lens = [min(x, 60000) for x in lens]  # (the oracle at level 9 is slow)
     cases = [piece(max(0, x)) for x in lens]
+    if BIG:
+        # the random streams first (they are the ones compared), padding streams of modest length behind them; one
+        # *_dev call for all, round trip of every stream checked on the device (tests/test_gpu_round3.py's helper)
+        import test_gpu_round3 as R3
+        cases = [c[:200000] for c in cases]
+        pad = R3.big_batch(int(rng.integers(1024, 1101)) - len(cases), seed=int(rng.integers(0, 1000)), max_len=40000)
+        allc = cases + pad
+        got_map = R3.device_round_trip(B, allc, level, fmt=fmt, dictionary=d, sample=range(len(cases)))
+        for i, s in enumerate(cases):
+            want = T.o_compress(s, zlib=bool(fmt), level=level, dict=dct[:dn] if dn else None)
+            assert got_map[i] == want, ("MISMATCH", level, fmt, dn, len(s))
+            checked += 1
+        rounds += 1
+        if rounds % 5 == 0:
+            print("%d big batches, %d streams checked, %.0f s" % (rounds, checked, time.time() - t0), flush=True)
+        continue
     got = B.compress_batch(cases, fmt=fmt, level=level, dictionary=d)
     for s, g in zip(cases, got):
         want = T.o_compress(s, zlib=bool(fmt), level=level, dict=dct[:dn] if dn else None)
