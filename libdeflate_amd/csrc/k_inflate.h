@@ -158,20 +158,25 @@ __device__ inline void br_align(BitReader &R, uint32_t lane) {  // SkipToByteBou
 // GetHuffmanForDecode (LD:2303-2344) over lens[0..nsym) (LDS).  Returns `left`:
 // 0 complete (also when there is no code at all, LD:2312-2314), > 0 incomplete,
 // < 0 over-subscribed.  Called by the whole wavefront (block = one wavefront).
-template <class DecTab>
+// W: wavefronts of the workgroup that decodes this stream (1, or more for k_inflate_wide).  With W > 1 every wavefront
+// runs the same wave-uniform code on the same data (so all of them take the same branches and meet at the same
+// barriers) and wavefront 0 alone makes the stores to LDS that must happen once.
+template <class DecTab, int W = 1>
 __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bitlen, int lut_bits,
-                           uint32_t lane, int mode) {
-  if (lane < 16) {
-    T.counts[lane] = 0;
-    T.running[lane] = 0;
-    T.offs[lane] = 0;
-    T.first[lane] = 0;
+                           uint32_t tid, int mode) {
+  const uint32_t lane = tid & 63;
+  const bool writer = W == 1 || tid < 64;
+  if (tid < 16) {
+    T.counts[tid] = 0;
+    T.running[tid] = 0;
+    T.offs[tid] = 0;
+    T.first[tid] = 0;
   }
-  for (int i = lane; i < DecTab::kSize; i += kWave) T.lut[i] = 0;
+  for (int i = tid; i < DecTab::kSize; i += W * kWave) T.lut[i] = 0;
   __syncthreads();
   for (int base = 0; base < nsym; base += kWave) {
     const int i = base + (int)lane;
-    if (i < nsym) atomicAdd(&T.counts[lens[i]], 1u);
+    if (writer && i < nsym) atomicAdd(&T.counts[lens[i]], 1u);
   }
   __syncthreads();
   if (T.counts[0] == (uint32_t)nsym) return 0;  // no codes: "complete", every decode fails
@@ -180,7 +185,7 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
     left = left * 2 - (int)T.counts[len];
     if (left < 0) return left;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     uint32_t off = 0, code = 0;
     for (int len = 1; len <= 15; len++) {
       code = (code + (len > 1 ? T.counts[len - 1] : 0u)) << 1;
@@ -201,7 +206,7 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
       mask &= ((l >> bit) & 1) ? bal : ~bal;
     }
     const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-    if (active) {
+    if (active && writer) {
       const uint32_t in_len = T.running[l] + rank;
       T.symbols[T.offs[l] + in_len] = (uint16_t)i;
       if ((int)l <= lut_bits) {
@@ -212,7 +217,7 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
       }
     }
     __syncthreads();
-    if (active && rank == 0) T.running[l] += (uint32_t)__popcll(mask);
+    if (active && writer && rank == 0) T.running[l] += (uint32_t)__popcll(mask);
     __syncthreads();
   }
   return left;
@@ -270,14 +275,16 @@ struct OutState {
 // codes).  *eob is set when the token was the end-of-block symbol.
 // The reference's buffer_size only differs from the output position after it reached 65536,
 // where no distance (<= 32768) can fail, so `dist > opos + ext` is the -11 test (LD:2406-2410).
+template <int W = 1>
 __device__ int decode_one(const LitTab &LT, const DistTab &DT, int lbits, int dbits, BitReader &R,
-                          OutState &O, uint32_t ext, uint32_t lane, bool *eob) {
+                          OutState &O, uint32_t ext, uint32_t tid, bool *eob) {
+  const uint32_t lane = tid & 63;
   const int symbol = decode_sym(LT, lbits, R, lane);
   *eob = symbol == 256;
   if (symbol < 0 || symbol > 285) return -10;
   if (symbol < 256) {
     if (O.opos >= O.cap) return kStatusOutputFull;
-    if (lane == 0) O.out[O.opos] = (uint8_t)symbol;
+    if (tid == 0) O.out[O.opos] = (uint8_t)symbol;
     O.opos++;
   } else if (symbol > 256) {
     const uint32_t ls = (uint32_t)symbol - 257;
@@ -301,11 +308,12 @@ __device__ int decode_one(const LitTab &LT, const DistTab &DT, int lbits, int db
     }
     if ((uint64_t)dist > O.opos + ext) return -11;
     if (O.opos + len > O.cap) return kStatusOutputFull;
-    // bytes this wave stored earlier must be visible to the loads below
+    // bytes this workgroup stored earlier must be visible to the loads below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (W > 1) __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int64_t src0 = (int64_t)O.opos - (int64_t)dist;
-    for (uint32_t k = lane; k < len; k += kWave) {
+    for (uint32_t k = tid; k < len; k += W * kWave) {
       const uint32_t j = dist >= len ? k : (k % dist);
       const int64_t si = src0 + j;
       const uint8_t byte = si < 0 ? O.dict[(int64_t)O.dlen + si] : O.out[si];
@@ -533,6 +541,392 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   }
 }
 
+// ------------------------------------------------------------------ the block body for few streams
+// DecodeUntilEndOfBlock (LD:2353-2445) by a workgroup of W wavefronts for ONE stream (a single string is
+// what every existing caller of the reference passes, and one wavefront per stream made a 128 KiB string slower than
+// the reference under LuaJIT).  A round covers W x 64 bit offsets: thread t decodes, speculatively, the token that
+// would start t bits after the current position (decode_block's code).  Which of these tokens are real is a walk
+// next = k + token_bits from the round's first bit.  decode_block makes that walk with the scalar unit, one dependent
+// v_readlane + add per token: some 130 cycles a token for a wavefront that runs alone, so widening the window alone
+// gained nothing (first version: 2.8 us per round of 256 bits, 5 us per 512).  Here the walk is made by pointer
+// jumping instead: every wavefront treats each of its 64 offsets as a possible entry point and doubles
+// (next, tokens visited, bytes produced) with ds_bpermute until every path has left the row (log2 of the tokens in
+// 64 bits: three or four steps), publishes exit and byte count per entry point, and the rows are then chained by W
+// dependent LDS reads.  The entry point of a row selects its 64-bit mask of real tokens; output offsets are a DPP
+// prefix sum over it.  The round's output is written in one pass, one thread per byte, as in decode_block; a match
+// that reads the round's own output (common once a round produces 100-200 bytes) or the dictionary is resolved
+// through an LDS image of the round's bytes, by chasing source offsets down to a byte that is a literal or older
+// output; only rounds that produce more than W x 64 bytes take the in-order path.  All wavefronts run the same
+// wave-uniform control flow on the same values (each keeps its own copy of the reader and of the positions), so they
+// take the same branches and meet at the same barriers.  Status codes and their order of checks are decode_block's
+// (Q11); the stopping token is resolved the same way.
+constexpr uint32_t kWideWin = 256;  // dwords of input staged per reload (8192 bits)
+
+template <int W>
+struct WideShared {
+  uint32_t in[kWideWin + 4];
+  uint32_t ex[W * kWave];    // per bit offset, as an entry point of its row: exit position | output bytes << kAccBits
+  uint32_t tk[W * kWave];    // per output offset: what the token starting there is made of
+  uint32_t S[2][W * 2 + 2];  // bit j: a token's output starts j bytes into the round's output (two rounds' worth)
+  uint16_t ob[W * kWave];    // the round's output bytes as far as they are known (| 0x100), for matches that read them
+  uint16_t sm[W * kWave];    // ... and, for a byte not yet known, the offset of the byte it copies
+  uint32_t stop[W];          // first stop event among each wavefront's 64: thread << 21 | its output offset; ~0 none
+  uint32_t stopf[W];         // flags << 8 | token bits of that token
+  uint32_t odd[W];           // a match of this wavefront's reads the round's own output or the dictionary
+  uint32_t cm[W * 2];        // in-order path: the committed matches of each wavefront's 64 offsets
+  uint32_t acc[W * kWave];   // in-order path: per bit offset the token's output offset
+};
+
+// v_readfirstlane as an unsigned value (the builtin returns int: widened or shifted it would sign-extend)
+__device__ inline uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); }
+// packed (position | bytes << kAccBits): positions stay below 2 x 64 + 48, kHardJ marks a token the walk cannot pass
+constexpr uint32_t kAccBits = 11, kAccMask = (1u << kAccBits) - 1u, kHardJ = 1024;
+
+__device__ inline void lds_barrier() {  // LDS only: stores and loads of the output in flight are not waited for
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// x + (x moved along by a DPP control; lanes without a source lane add 0)
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_add(uint32_t x) {
+  return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ inline uint32_t wave_inclusive_sum(uint32_t x) {
+  x = dpp_add<0x111, 0xF>(x);  // row_shr:1
+  x = dpp_add<0x112, 0xF>(x);  // row_shr:2
+  x = dpp_add<0x114, 0xF>(x);  // row_shr:4
+  x = dpp_add<0x118, 0xF>(x);  // row_shr:8   -> sums within rows of 16
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_add<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
+#ifdef LDH_WIDE_STAMPS  // diagnostic builds only: shader cycles per phase of a round (workgroup 0, wavefront 0)
+__device__ unsigned long long g_wide_stamps[16];
+#define LDH_STAMP(k_)                                              \
+  {                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    st_acc[k_] += now_ - st_t;                                     \
+    st_t = now_;                                                   \
+  }
+#else
+#define LDH_STAMP(k_)
+#endif
+
+template <int W>
+__device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader &R, OutState &O, uint32_t tid,
+                                 WideShared<W> &Sh) {
+  constexpr uint32_t NT = W * kWave;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint32_t ext = 0;
+  if (O.dict && !O.dict_loaded) {  // LD:2367-2377
+    ext = O.dlen;
+    O.dict_loaded = true;
+  }
+  const uint64_t nbits = (uint64_t)R.nbytes * 8;
+  const uint64_t skip_bits = (uint64_t)R.skip * 8;
+  const uint32_t cap = (uint32_t)O.cap;
+  uint8_t *const out = O.out;
+  uint32_t op = (uint32_t)O.opos;  // output position (uniform)
+  uint64_t bp = R.consumed;        // bits consumed so far (uniform); current only while !have
+  int64_t bp0 = 0;                 // bits consumed = bp0 + rel while the window is valid
+  uint32_t rel = 0;                // bit offset of the current position in the window
+  uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
+  bool have = false;
+  uint32_t round = 0;
+  if (tid < 2 * (W * 2 + 2)) (&Sh.S[0][0])[tid] = 0;
+#ifdef LDH_WIDE_STAMPS
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+  struct StampOut {
+    unsigned long long *a;
+    uint32_t tid;
+    uint32_t *rounds;
+    __device__ ~StampOut() {
+      if (tid == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 10; i++) atomicAdd(&g_wide_stamps[i], a[i]);
+        atomicAdd(&g_wide_stamps[15], (unsigned long long)*rounds);
+      }
+    }
+  } stamp_out{st_acc, tid, &round};
+#endif
+  for (;; round++) {
+    LDH_STAMP(9)
+    if (!have || rel + NT + 64 > kWideWin * 32) {
+      if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
+      const uint64_t absbit = skip_bits + bp;
+      const uint32_t cw0 = (uint32_t)(absbit >> 5);  // first dword (relative to R.base) held in Sh.in
+      lds_barrier();
+      const uint64_t end = (uint64_t)R.skip + R.nbytes;
+      for (uint32_t i = tid; i < kWideWin + 4; i += NT) {
+        const uint64_t first = ((uint64_t)cw0 + i) * 4;
+        uint32_t x = 0;
+        if (first < end) {
+          x = R.base[cw0 + i];
+          if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
+        }
+        Sh.in[i] = x;
+      }
+      lds_barrier();
+      rel = (uint32_t)absbit & 31;
+      bp0 = (int64_t)bp - (int64_t)rel;
+      const int64_t l = (int64_t)nbits - bp0;
+      lim = l <= 0 ? 0u : (l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)l);  // (l <= 0: see decode_block)
+      have = true;
+    }
+    uint32_t *const S = Sh.S[round & 1], *const S_next = Sh.S[(round & 1) ^ 1];
+    LDH_STAMP(0)
+    // ---- every thread decodes the token starting `tid` bits ahead (decode_block's code)
+    const uint32_t bit = rel + tid;
+    const uint32_t di = bit >> 5, sh = bit & 31;
+    const uint32_t w0 = Sh.in[di], w1 = Sh.in[di + 1], w2 = Sh.in[di + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const uint64_t win = ((uint64_t)hi << 32) | lo;
+    const uint32_t e = LT.lut[lo & (LitTab::kSize - 1)];
+    const uint32_t l1 = e & 15;
+    const bool is_len = (e >> 15) != 0;
+    const uint32_t sym = (e >> 4) & 511;  // meaningful when !is_len
+    const bool is_lit = !is_len & (sym < 256), is_eob = !is_len & (sym == 256);
+    bool slow = e == 0;
+    bool bad = !is_len & (sym == 511);
+    const uint32_t leb = is_len ? (e >> 4) & 7 : 0u;
+    const uint32_t mlen = 3 + ((e >> 7) & 255) + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
+    const uint32_t t = l1 + leb;
+    const uint32_t din = (uint32_t)(win >> t);
+    const uint32_t e2 = DT.lut[din & (DistTab::kSize - 1)];
+    const uint32_t l2 = e2 & 15, deb = (e2 >> 4) & 15;
+    slow = slow | (is_len & (e2 == 0));
+    bad = bad | (is_len & ((e2 >> 10) != 0));
+    const uint32_t dist = 1 + (((e2 >> 8) & 3) << deb) + ((din >> l2) & ((1u << deb) - 1u));
+    const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
+    const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
+    const bool hard = slow | bad | is_eob;
+    // ---- pointer jumping inside the wavefront's row of 64 offsets: X = where the path from this offset stands
+    // (row coordinates; 64 and more: it has left the row; kHardJ: it ended at a token that cannot be passed) | the
+    // bytes its tokens produce; V = the offsets it visited
+    uint32_t X = (hard ? kHardJ : lane + tok_bits) | (out_len << kAccBits);
+    asm volatile("" : "+v"(X));
+    LDH_STAMP(1)
+    uint32_t Vlo = lane < 32 ? 1u << lane : 0u, Vhi = lane >= 32 ? 1u << (lane - 32) : 0u;
+    while (ballot64((X & kAccMask) < kWave)) {  // (uniform)
+      const uint32_t j = X & kAccMask;
+      const bool go = j < kWave;
+      const int addr = (int)((go ? j : lane) << 2);
+      const uint32_t Xs = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)X);
+      const uint32_t Ls = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)Vlo);
+      const uint32_t Hs = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)Vhi);
+      if (go) {
+        Vlo |= Ls;
+        Vhi |= Hs;
+        X = (Xs & kAccMask) | ((X >> kAccBits) + (Xs >> kAccBits)) << kAccBits;
+      }
+    }
+    LDH_STAMP(2)
+    Sh.ex[tid] = X;
+    lds_barrier();
+    LDH_STAMP(3)
+    // ---- chain the rows: entry point and output offset of every row, this wavefront's among them.  Every wavefront
+    // fetches all W rows of (exit | bytes) at once, one row per register, and then hops from row to row with
+    // v_readlane (the hops through LDS, one dependent read each, were a third of a round)
+    uint32_t exr[W];
+#pragma unroll
+    for (int r = 0; r < W; r++) exr[r] = Sh.ex[r * kWave + lane];
+    uint32_t ent = 0, base = 0, my_ent = 0, my_base = 0;
+    bool alive = true, my_alive = false;
+#pragma unroll
+    for (int r = 0; r < W; r++) {
+      if ((uint32_t)r == wave) {
+        my_ent = ent;
+        my_base = base;
+        my_alive = alive;
+      }
+      // (selects, no branches: `ent` stays a valid lane when the walk has ended)
+      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)exr[r], (int)ent);
+      const uint32_t j = x & kAccMask;
+      const bool on = alive & (j < kHardJ);
+      base += alive ? x >> kAccBits : 0u;
+      ent = on ? j - kWave : ent;
+      alive = on;
+    }
+    const uint32_t total_out = base, total_bits = NT + ent;  // (total_bits: meaningful while alive)
+    LDH_STAMP(4)
+    // the real tokens of this row, their output offsets
+    const uint32_t mlo = my_alive ? (uint32_t)__builtin_amdgcn_readlane((int)Vlo, (int)my_ent) : 0u;
+    const uint32_t mhi = my_alive ? (uint32_t)__builtin_amdgcn_readlane((int)Vhi, (int)my_ent) : 0u;
+    const bool is_tok = (((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0;
+    const uint32_t contrib = is_tok ? out_len : 0u;
+    const uint32_t my_off = my_base + wave_inclusive_sum(contrib) - contrib;
+    // ---- stop events, in the reference's order of checks for one token
+    const uint32_t my_pos = op + my_off;
+    const bool err11 = is_len & (dist > my_pos + ext);  // LD:2406-2410
+    const bool full = my_pos + out_len > cap;
+    const bool exh = bit + tok_bits > lim;              // LD:2428
+    const unsigned long long stops = ballot64(is_tok & (hard | err11 | full | exh));
+    // a match that reads this round's own output (that includes every self-overlapping one) or the dictionary
+    const bool odd = is_tok & is_len & ((my_pos + mlen > op + dist) | (dist > my_pos));
+    const unsigned long long odds = ballot64(odd);
+    const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) | (exh ? 16u : 0u) |
+                        (is_eob ? 32u : 0u);
+    {
+      const uint32_t sl = stops ? (uint32_t)__builtin_ctzll(stops) : 0u;
+      const uint32_t s_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)sl);
+      const uint32_t s_fl = (uint32_t)__builtin_amdgcn_readlane((int)(fl << 8 | tok_bits), (int)sl);
+      if (lane == 0) {
+        Sh.stop[wave] = stops ? ((wave * kWave + sl) << 21) | s_off : 0xFFFFFFFFu;
+        Sh.stopf[wave] = s_fl;
+        Sh.odd[wave] = odds != 0;
+      }
+    }
+    if (is_tok & (my_off < NT)) {
+      Sh.tk[my_off] = is_len ? (0x80000000u | (dist - 1)) : sym;
+      atomicOr(&S[my_off >> 5], 1u << (my_off & 31));
+    }
+    if (tid < W * 2 + 2) S_next[tid] = 0;
+    LDH_STAMP(5)
+    // every store of earlier rounds must have landed before a match source among them is read
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    lds_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LDH_STAMP(6)
+    uint32_t st_min, st_fl, any_odd;
+    {
+      uint32_t sv[W], fv[W], ov[W];
+#pragma unroll
+      for (int r = 0; r < W; r++) {
+        sv[r] = Sh.stop[r];
+        fv[r] = Sh.stopf[r];
+        ov[r] = Sh.odd[r];
+      }
+      uint32_t m = sv[0], f = fv[0], o = ov[0];
+#pragma unroll
+      for (int r = 1; r < W; r++) {
+        f = sv[r] < m ? fv[r] : f;
+        m = sv[r] < m ? sv[r] : m;
+        o |= ov[r];
+      }
+      st_min = rfl(m);
+      st_fl = rfl(f);
+      any_odd = rfl(o);
+    }
+    const uint32_t first = st_min == 0xFFFFFFFFu ? NT : st_min >> 21;
+    const uint32_t n_out = first == NT ? total_out : st_min & 0x1FFFFFu;
+    LDH_STAMP(7)
+    if (n_out <= NT) {
+      // one thread per output byte: its token is the highest bit of S at or below its offset (bit 0 is always set)
+      uint32_t v = 0, src = 0;
+      bool known = true;
+      if (tid < n_out) {
+        uint32_t w = tid >> 5;
+        uint32_t m = S[w] & (0xFFFFFFFFu >> (31 - (tid & 31)));
+        while (m == 0) m = S[--w];
+        const uint32_t tok_off = w * 32 + 31 - (uint32_t)__clz((int)m);
+        const uint32_t info = Sh.tk[tok_off];
+        v = info;
+        if (info >> 31) {
+          const uint32_t d = (info & 0xFFFFu) + 1;
+          if (!any_odd) {  // (uniform) every source is older output
+            v = out[op + tid - d];
+          } else {
+            // byte i of a match copies byte i mod dist of the dist bytes before the match (so a run costs one hop)
+            const uint32_t i = tid - tok_off;
+            const uint32_t at = tok_off + (i >= d ? i % d : i);  // its source, `d` bytes before this offset of the round
+            if (at >= d) {
+              known = false;
+              src = at - d;
+            } else {
+              const uint32_t back = d - at;  // bytes before the round's first
+              v = back <= op ? out[op - back] : O.dict[O.dlen - (back - op)];
+            }
+          }
+        }
+      }
+      if (any_odd) {  // (uniform)
+        Sh.ob[tid] = known ? (uint16_t)((v & 0xFFu) | 0x100u) : (uint16_t)0;
+        Sh.sm[tid] = (uint16_t)src;
+        lds_barrier();
+        if (!known) {  // down the chain of sources to a byte that is known: sources lie strictly below
+          uint32_t r = Sh.ob[src];
+          while (!(r & 0x100u)) {
+            src = Sh.sm[src];
+            r = Sh.ob[src];
+          }
+          v = r;
+        }
+      }
+      if (tid < n_out) out[op + tid] = (uint8_t)v;
+    } else {
+      // more bytes than threads: in order -- literals by their threads, then every match by the whole workgroup, each
+      // one seeing what was stored before it
+      const bool commit = is_tok & (tid < first);
+      if (commit & is_lit) out[my_pos] = (uint8_t)sym;
+      const unsigned long long cmm = ballot64(commit & is_len);
+      Sh.tk[tid] = (mlen << 16) | (dist - 1);
+      Sh.acc[tid] = my_off;
+      if (lane == 0) {
+        Sh.cm[wave * 2] = (uint32_t)cmm;
+        Sh.cm[wave * 2 + 1] = (uint32_t)(cmm >> 32);
+      }
+      lds_barrier();
+#pragma unroll 1
+      for (int r = 0; r < W; r++) {
+        unsigned long long mm = ((unsigned long long)rfl(Sh.cm[r * 2 + 1]) << 32) | rfl(Sh.cm[r * 2]);
+        while (mm) {
+          const uint32_t j = (uint32_t)r * kWave + (uint32_t)__builtin_ctzll(mm);
+          mm &= mm - 1;
+          const uint32_t info = rfl(Sh.tk[j]);
+          const uint32_t len = info >> 16, d = (info & 0xFFFFu) + 1;
+          const uint32_t dst = op + rfl(Sh.acc[j]);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          lds_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (d >= len && d <= dst) {  // (uniform) no overlap with itself, source in the output
+            for (uint32_t i = tid; i < len; i += NT) out[dst + i] = out[dst - d + i];
+          } else {
+            for (uint32_t i = tid; i < len; i += NT) {
+              const uint32_t a = dst + (d >= len ? i : (i % d));
+              out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
+            }
+          }
+        }
+      }
+      lds_barrier();  // (tk and cm are rewritten by the next round)
+    }
+    LDH_STAMP(8)
+    if (first == NT) {  // the whole window was consumed
+      op += total_out;
+      rel += total_bits;
+      continue;
+    }
+    // ---- the stopping token
+    const uint32_t f = st_fl >> 8, fbits = st_fl & 0xFFu;
+    op += n_out;
+    O.opos = op;
+    rel += first;
+    bp = (uint64_t)(bp0 + (int64_t)rel);
+    if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
+      br_seek_bits(R, bp, lane);
+      bool eob = false;
+      const int st = decode_one<W>(LT, DT, 0, 0, R, O, ext, tid, &eob);
+      if (st != 0) return st;
+      if (eob) return 0;
+      bp = R.consumed;
+      op = (uint32_t)O.opos;
+      have = false;
+      continue;
+    }
+    R.consumed = bp;
+    if (f & 2) return -10;
+    if (f & 4) return -11;
+    if (f & 8) return kStatusOutputFull;
+    bp += fbits;
+    R.consumed = bp;
+    if (f & 16) return 2;
+    // end of block: hand the position back to the wave-uniform reader
+    br_seek_bits(R, bp, lane);
+    return 0;
+  }
+}
+
 // The block body as a function of its own.  Inlined at its two call sites it shares k_inflate's scalar registers
 // with the header code around it, and the round loop reloads spilled ones through v_readlane / v_writelane: with the
 // chip full of waves (instruction issue is the bound) the call is faster, 11.0 -> 10.6 ms per GiB at 8192 streams
@@ -540,10 +934,13 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
 // faster with the inlined body (one 16 MiB stream: 520 against 570 ms).  Hence two kernels, chosen by batch size
 // (the call is kept a call by a statement attribute; a noinline wrapper around the inlinable body sent this
 // compiler's backend into "Illegal instruction detected" on the LDS pointers' address-space casts).
-template <bool BODY_CALL>
+// W: wavefronts per stream (1: k_inflate / k_inflate_alone; more: k_inflate_wide, whose block body is decode_block_wide;
+// everything around the body is the same wave-uniform code, run by all W wavefronts alike, stores made once).
+template <int W, bool BODY_CALL>
 __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT, DistTab &DT, uint8_t *lens, uint32_t *s_in,
-                                               uint32_t *s_tk) {
-  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+                                               uint32_t *s_tk, WideShared<(W > 1 ? W : 2)> *Sh) {
+  constexpr uint32_t NT = W * kWave;
+  const uint32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const uint64_t off = A.in_len ? (uint64_t)s * A.in_stride : A.in_off[s];
   const uint32_t n = A.in_len ? A.in_len[s] : (uint32_t)(A.in_off[s + 1] - off);
   BitReader R;
@@ -592,19 +989,21 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
         if (O.opos + len > O.cap) { status = kStatusOutputFull; break; }
         const uint64_t ipos = R.consumed >> 3;
         const uint8_t *src = A.in + off + ipos;
-        for (uint32_t k = lane; k < len; k += kWave) O.out[O.opos + k] = src[k];
+        for (uint32_t k = tid; k < len; k += NT) O.out[O.opos + k] = src[k];
         O.opos += len;
         br_seek(R, ipos + len, lane);
       } else if (type == 1) {  // LD:2496-2501
         if (fixed_ready != 1) {
-          for (int i = lane; i < 288; i += kWave) lens[i] = (uint8_t)fixed_lit_bits(i);
-          if (lane < 32) lens[288 + lane] = 5;
+          for (int i = tid; i < 288; i += NT) lens[i] = (uint8_t)fixed_lit_bits(i);
+          if (tid < 32) lens[288 + tid] = 5;
           __syncthreads();
-          build_table(LT, lens, 288, 9, LitTab::kBits, lane, kLutLitLen);
-          build_table(DT, lens + 288, 32, 5, DistTab::kBits, lane, kLutDist);
+          build_table<LitTab, W>(LT, lens, 288, 9, LitTab::kBits, tid, kLutLitLen);
+          build_table<DistTab, W>(DT, lens + 288, 32, 5, DistTab::kBits, tid, kLutDist);
           fixed_ready = 1;
         }
-        if (BODY_CALL) {
+        if constexpr (W > 1) {
+          status = decode_block_wide<W>(LT, DT, R, O, tid, *Sh);
+        } else if (BODY_CALL) {
           [[clang::noinline]] status = decode_block<0>(LT, DT, R, O, lane, s_in, s_tk);
         } else {
           status = decode_block<1>(LT, DT, R, O, lane, s_in, s_tk);
@@ -617,16 +1016,16 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
         if (nlen > 286 || ndist > 30) { status = -3; break; }
         const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         __syncthreads();
-        if (lane < 19) lens[lane] = 0;
+        if (tid < 19) lens[tid] = 0;
         __syncthreads();
         for (uint32_t i = 0; i < ncode; i++) {
           const uint32_t v = br_read(R, 3, lane);
-          if (lane == 0) lens[order[i]] = (uint8_t)v;
+          if (tid == 0) lens[order[i]] = (uint8_t)v;
         }
         __syncthreads();
-        if (build_table(DT, lens, 19, 7, 7, lane, kLutPlain) != 0) { status = -4; break; }
+        if (build_table<DistTab, W>(DT, lens, 19, 7, 7, tid, kLutPlain) != 0) { status = -4; break; }
         __syncthreads();
-        for (int i = lane; i < 320; i += kWave) lens[i] = 0;
+        for (int i = tid; i < 320; i += NT) lens[i] = 0;
         __syncthreads();
         uint32_t index = 0;
         uint32_t prev_len = 0;  // lens[index-1], tracked in a register
@@ -634,7 +1033,7 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
           int symbol = decode_sym(DT, 7, R, lane);
           if (symbol < 0) { status = symbol; break; }
           if (symbol < 16) {
-            if (lane == 0) lens[index] = (uint8_t)symbol;
+            if (tid == 0) lens[index] = (uint8_t)symbol;
             prev_len = (uint32_t)symbol;
             index++;
           } else {
@@ -649,7 +1048,7 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
               rep = 11 + br_read(R, 7, lane);
             }
             if (index + rep > nlen + ndist) { status = -6; break; }
-            for (uint32_t k = lane; k < rep; k += kWave) lens[index + k] = (uint8_t)bitlen;
+            for (uint32_t k = tid; k < rep; k += NT) lens[index + k] = (uint8_t)bitlen;
             prev_len = bitlen;
             index += rep;
           }
@@ -660,13 +1059,15 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
         // the distance lengths follow the nlen literal/length lengths; move them apart
         const uint8_t dl = lane < ndist ? lens[nlen + lane] : 0;
         __syncthreads();
-        if (lane < 32) lens[320 + lane] = dl;
+        if (tid < 32) lens[320 + tid] = dl;
         __syncthreads();
-        int err = build_table(LT, lens, (int)nlen, 15, LitTab::kBits, lane, kLutLitLen);
+        int err = build_table<LitTab, W>(LT, lens, (int)nlen, 15, LitTab::kBits, tid, kLutLitLen);
         if (err != 0 && (err < 0 || nlen != LT.counts[0] + LT.counts[1])) { status = -7; break; }
-        err = build_table(DT, lens + 320, (int)ndist, 15, DistTab::kBits, lane, kLutDist);
+        err = build_table<DistTab, W>(DT, lens + 320, (int)ndist, 15, DistTab::kBits, tid, kLutDist);
         if (err != 0 && (err < 0 || ndist != DT.counts[0] + DT.counts[1])) { status = -8; break; }
-        if (BODY_CALL) {
+        if constexpr (W > 1) {
+          status = decode_block_wide<W>(LT, DT, R, O, tid, *Sh);
+        } else if (BODY_CALL) {
           [[clang::noinline]] status = decode_block<0>(LT, DT, R, O, lane, s_in, s_tk);
         } else {
           status = decode_block<1>(LT, DT, R, O, lane, s_in, s_tk);
@@ -683,7 +1084,7 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
     }
   } while (false);
 
-  if (lane == 0) {
+  if (tid == 0) {
     const int64_t left = br_left(R);
     A.status[s] = status;
     A.out_len[s] = (uint32_t)O.opos;
@@ -701,11 +1102,25 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &A, LitTab &LT,
     __shared__ uint8_t lens[320 + 32];                                                                        \
     __shared__ uint32_t s_in[kWave + 4];                                                                      \
     __shared__ uint32_t s_tk[kWave];                                                                          \
-    inflate_stream<call_>(A, LT, DT, lens, s_in, s_tk);                                                       \
+    inflate_stream<1, call_>(A, LT, DT, lens, s_in, s_tk, nullptr);                                           \
   }
 LDH_INFLATE_KERNEL(k_inflate, true)         // the block body as a call: batches that fill the chip
 LDH_INFLATE_KERNEL(k_inflate_alone, false)  // inlined: few streams
 #undef LDH_INFLATE_KERNEL
+
+// Few streams: a workgroup of W wavefronts per stream (decode_block_wide).
+#define LDH_INFLATE_WIDE_KERNEL(name_, W_)                                              \
+  __global__ __launch_bounds__(W_ * kWave) void name_(InflateArgs A) {                  \
+    __shared__ LitTab LT;                                                               \
+    __shared__ DistTab DT;                                                              \
+    __shared__ uint8_t lens[320 + 32];                                                  \
+    __shared__ WideShared<W_> Sh;                                                       \
+    inflate_stream<W_, false>(A, LT, DT, lens, nullptr, nullptr, &Sh);                  \
+  }
+LDH_INFLATE_WIDE_KERNEL(k_inflate_wide2, 2)
+LDH_INFLATE_WIDE_KERNEL(k_inflate_wide4, 4)
+LDH_INFLATE_WIDE_KERNEL(k_inflate_wide8, 8)
+#undef LDH_INFLATE_WIDE_KERNEL
 
 // DecompressZlibInternal's final comparison (LD:2717-2722)
 __global__ void k_zlib_check(uint32_t count, const uint32_t *expect, const uint32_t *actual,

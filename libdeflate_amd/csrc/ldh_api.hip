@@ -456,9 +456,23 @@ int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off
   A.bytes_left = d_bytes_left;
   A.status = d_status;
   A.expect_adler = expect;
-  // (the block body as a call when the batch fills the chip with waves, inlined when they run nearly alone)
+  // One wavefront per stream when the batch has streams enough to keep the chip busy that way (k_inflate: the block
+  // body as a call from 4096 streams on, inlined below that); fewer streams get a workgroup of four or eight
+  // wavefronts each, a round speculating on 256 / 512 bit offsets (decode_block_wide).  Measured on 128 KiB streams
+  // (tools/inflate_rate.py, ms for 1 / 256 / 1024 / 2048 / 4096 streams): one wavefront 4.1 / 4.4 / 4.8 / 5.8 / 7.3,
+  // four 2.3 / 2.5 / 3.3 / 6.6 / 12.8, eight 1.6 / 1.8 / 4.4 / 8.7 / 17.  LDH_INFLATE_WAVES=1/2/4/8 forces a form.
   static const int body_call_min = getenv("LDH_INFLATE_CALL_MIN") ? atoi(getenv("LDH_INFLATE_CALL_MIN")) : 4096;
-  if (count >= (size_t)body_call_min)
+  static const int wide4_max = getenv("LDH_INFLATE_WIDE4_MAX") ? atoi(getenv("LDH_INFLATE_WIDE4_MAX")) : 1792;
+  static const int wide8_max = getenv("LDH_INFLATE_WIDE8_MAX") ? atoi(getenv("LDH_INFLATE_WIDE8_MAX")) : 640;
+  const char *force = getenv("LDH_INFLATE_WAVES");
+  const int waves = force ? atoi(force) : (count < (size_t)wide8_max ? 8 : (count < (size_t)wide4_max ? 4 : 1));
+  if (waves == 8)
+    LAUNCH("k_inflate", k_inflate_wide8, (uint32_t)count, 8 * kWave, 0, A);
+  else if (waves == 2)
+    LAUNCH("k_inflate", k_inflate_wide2, (uint32_t)count, 2 * kWave, 0, A);
+  else if (waves == 4)
+    LAUNCH("k_inflate", k_inflate_wide4, (uint32_t)count, 4 * kWave, 0, A);
+  else if (count >= (size_t)body_call_min)
     LAUNCH("k_inflate", k_inflate, (uint32_t)count, kWave, 0, A);
   else
     LAUNCH("k_inflate", k_inflate_alone, (uint32_t)count, kWave, 0, A);
@@ -1643,6 +1657,17 @@ int ldh_timer_stop(double *ms) {
 
 // ---- inspection ---------------------------------------------------------------------
 uint64_t ldh_debug_alloc_count(void) { return g_allocs.load(); }
+#ifdef LDH_WIDE_STAMPS  // diagnostic builds only (not declared in the header)
+int ldh_debug_wide_stamps(unsigned long long *dst, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(ldh::g_wide_stamps), 16 * 8);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(ldh::g_wide_stamps), z, 16 * 8);
+  }
+  return 0;
+}
+#endif
 int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes) {
   CTX_ENTER(cx);
   if (!cx.have_last || stream >= cx.last.count) return fail(LDH_E_ARG, "no such stream in the last batch");
