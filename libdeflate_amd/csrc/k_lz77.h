@@ -1567,6 +1567,404 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   }
 }
 
+// ------------------------------------------------------------------ levels 1-2, second form: k_cand_lists + k_lz_greedy2
+//   k_lz_greedy above pays one dependent round trip to global memory per token and is bound by
+// the scalar unit besides (113 VALU + 135 SALU per token, one token at a time).  The walk over a stream must stay
+// serial (Q4: which positions are in the chains depends on the tokens before), but neither the candidates of a
+// position nor their match lengths depend on the parse -- only which of them count as inserted does.  So:
+//   k_cand_lists   (all positions in parallel, window and links in LDS like k_match_lazy) writes for every position
+//                  its K nearest same-trigram predecessors inside the window, nearest first: distance - 1 (15 bits) and
+//                  the match length, capped at 18, as a nibble.  K = 8 at level 1, 16 at level 2 (the walk wants 4 / 8
+//                  inserted candidates; on text 86 % / 85 % of the searched positions are decided inside the list).
+//   k_lz_greedy2   one wavefront per stream takes 64 consecutive positions a round.  Phase 1, all lanes: lane i reads
+//                  the list of position c0 + i (consecutive lanes, consecutive memory: a stream, not a gather) and
+//                  runs LD:1362-1398 on it against the "was inserted" bitmap (a ring of 32768 bits in LDS); everything
+//                  before c0 is final, so the result is final too unless a candidate lies inside the round's own 64
+//                  positions (then the lane is marked uncertain) or the list ends with the chain still going on
+//                  (needs more).  Phase 2, wave-uniform: the walk x -> x + token length over the 64 positions picks
+//                  the real tokens; an uncertain lane that the walk comes by is evaluated again (by then everything
+//                  before it is final), a lane that needs more goes on through the list of its last candidate (its
+//                  candidates' lengths then come from byte compares, 16 candidates a trip, as in k_lz_greedy).
+//                  Tokens are gathered in a register and stored 64 at a time.
+// Per 64 positions the serial part is the ~15 real tokens' bookkeeping; the candidate evaluation, done for all 64
+// positions whether the parse comes by or not, is what the lanes are for.  No dictionary (batches with one, and
+// level 3, whose walk wants 32 inserted candidates, keep k_lz_greedy).
+constexpr uint32_t kCandTile = 16384;
+constexpr uint32_t kCandByteCap = kWindow + kCandTile + 288;
+constexpr uint32_t kCandPrevCap = kWindow + kCandTile + 8;
+constexpr uint32_t kCandLdsBytes = kCandByteCap + 2 * kCandPrevCap;
+constexpr int kCandThreads = 1024, kCandThreadsNarrow = 256;
+constexpr uint32_t kCandLenCap = 18;  // lengths are stored as min(L, 18) - 3
+
+// per stream: [nvp * 2K bytes of distances][nvp * K/2 bytes of length nibbles] in bufC
+__host__ __device__ inline size_t cand_stream_bytes(uint32_t nvp, int K) { return (size_t)nvp * (size_t)(2 * K + K / 2); }
+
+template <int K, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_cand_lists(Batch B, uint32_t tiles_per_stream, uint32_t lds_byte_cap) {
+  extern __shared__ uint32_t smem[];
+  uint32_t *lbytes = smem;
+  uint16_t *lprev = (uint16_t *)(smem + lds_byte_cap / 4);
+  const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t s = work / tiles_per_stream, tile = work % tiles_per_stream;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = stream_len(B, s);
+  const uint32_t q0 = tile * kCandTile;
+  if (q0 >= n) return;
+  const uint32_t q1 = q0 + kCandTile < n ? q0 + kCandTile : n;
+  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint16_t *prevd = B.prevd + (size_t)s * B.nvp;
+  uint8_t *cbase = (uint8_t *)B.bufC + (size_t)s * cand_stream_bytes(B.nvp, K);
+  uint32_t *dout = (uint32_t *)cbase;                               // K/2 dwords per position
+  uint32_t *nout = (uint32_t *)(cbase + (size_t)B.nvp * 2 * K);     // K/8 dwords per position
+  const uint32_t alloc_end = n + kVPad;
+  const uint32_t wbase = (q0 > kWindow ? q0 - kWindow : 0u) & ~3u;
+  {  // stage bytes [wbase, q1 + 280) and links [wbase, q1): as k_match_lazy does ("no link" becomes a hop of 65535)
+    const uint32_t nb = (q1 + 280 - wbase + 3) / 4;
+    const uint32_t *gsrc = (const uint32_t *)(V + wbase);
+    for (uint32_t i = tid; i < nb; i += THREADS) lbytes[i] = (wbase + 4 * i + 4 <= alloc_end) ? gsrc[i] : 0u;
+    const uint32_t np = (q1 - wbase + 1) / 2;
+    const uint32_t *psrc = (const uint32_t *)(prevd + wbase);
+    uint32_t *pdst = (uint32_t *)lprev;
+    for (uint32_t i = tid; i < np; i += THREADS) {
+      uint32_t x = psrc[i];
+      x |= (x & 0xFFFFu) ? 0u : 0xFFFFu;
+      x |= (x >> 16) ? 0u : 0xFFFF0000u;
+      pdst[i] = x;
+    }
+  }
+  __syncthreads();
+  const uint32_t blk0 = (q0 + 1) <= kFirstBlock ? 0u : 1u + (q0 - kFirstBlock) / kNextBlock;
+  const uint32_t be_lo = block_end(blk0, n), be_hi = block_end(blk0 + 1, n);
+  for (uint32_t q = q0 + tid; q < q1; q += THREADS) {
+    const uint32_t p = q + 1, be = p <= be_lo ? be_lo : be_hi;
+    const uint32_t vb = q - wbase;
+    const int32_t lo = (int32_t)vb - (int32_t)kWindow;  // LD:1365
+    uint32_t dd[K / 2];
+    uint32_t nb[K / 8];
+#pragma unroll
+    for (int i = 0; i < K / 2; i++) dd[i] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < K / 8; i++) nb[i] = 0;
+    // (every position gets its list, also the last two of a block, which LD:1349 does not search: k_lz_greedy2 goes on
+    // through the lists of candidates when a chain is longer than K, and those positions are chain members like any)
+    bool run = true;
+    uint32_t maxlen = be + 1 - p;
+    maxlen = maxlen > kMaxMatch ? kMaxMatch : (maxlen < 3 ? 3u : maxlen);
+    const uint64_t tw0 = lds_load8(lbytes, vb + 3), tw1 = lds_load8(lbytes, vb + 11);
+    uint32_t c = vb;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t d = lprev[c];
+      const uint32_t cn = c - d;
+      run = run & ((int32_t)cn >= lo);
+      c = run ? cn : c;
+      const uint64_t x = lds_load8(lbytes, c + 3) ^ tw0;
+      uint32_t L = 3 + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u);
+      if (__builtin_amdgcn_ballot_w64(run & (x == 0))) {  // (uniform: the second eight bytes are rarely needed)
+        const uint64_t y = lds_load8(lbytes, c + 11) ^ tw1;
+        L = x ? L : 11 + (y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8u);
+      }
+      L = L > maxlen ? maxlen : L;
+      L = L > kCandLenCap ? kCandLenCap : L;
+      const uint32_t ent = run ? vb - c - 1 : 0xFFFFu;
+      dd[k >> 1] = (k & 1) ? ((dd[k >> 1] & 0xFFFFu) | (ent << 16)) : ((dd[k >> 1] & 0xFFFF0000u) | ent);
+      nb[k >> 3] |= run ? (L - 3) << (4 * (k & 7)) : 0u;
+    }
+    // bit 15 of the last entry: the chain goes on inside the window
+    {
+      const uint32_t d = lprev[c];
+      const bool more = run & ((int32_t)(c - d) >= lo);
+      dd[K / 2 - 1] |= more ? 0x80000000u : 0u;
+    }
+    if (K == 8) {
+      *(uint4 *)(dout + (size_t)q * 4) = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+      nout[q] = nb[0];
+    } else {
+      *(uint4 *)(dout + (size_t)q * 8) = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+      *(uint4 *)(dout + (size_t)q * 8 + 4) = make_uint4(dd[4 % (K / 2)], dd[5 % (K / 2)], dd[6 % (K / 2)], dd[7 % (K / 2)]);
+      *(uint2 *)(nout + (size_t)q * 2) = make_uint2(nb[0], nb[1 % (K / 8)]);
+    }
+  }
+}
+
+// The bitmap is written and read by the lanes of ONE wavefront, and LDS operations of a wavefront execute in order: all
+// that is needed between a write and the reads behind it is that the compiler keeps them in that order.  (A workgroup
+// fence -- or __syncthreads(), as in k_lz_greedy -- also waits for every global store and load in flight: with a token
+// store before it, that was a round trip to memory per token, 23 of this kernel's first 47 ms per GiB.)
+__device__ inline void lds_order() { asm volatile("" ::: "memory"); }
+
+template <int K>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz_greedy2(Batch B) {
+  __shared__ uint32_t s_ins[1024];  // bit (q mod 32768): stream position q is in a hash chain (LD:1347)
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  if (s >= B.count) return;
+  const uint32_t n = stream_len(B, s);
+  const uint8_t *V = B.vbuf + (size_t)s * (B.nvp + kVPad);
+  const uint8_t *cbase = (const uint8_t *)B.bufC + (size_t)s * cand_stream_bytes(B.nvp, K);
+  const uint32_t *dg = (const uint32_t *)cbase;
+  const uint32_t *ng = (const uint32_t *)(cbase + (size_t)B.nvp * 2 * K);
+  const uint16_t *dg16 = (const uint16_t *)cbase;
+  const LevelCfg cfg = level_cfg(B.level);
+  const uint32_t nice = (uint32_t)cfg.nice, max_chain = (uint32_t)cfg.max_chain;
+  const uint32_t max_insert = (uint32_t)cfg.max_lazy;  // max_insert_length for these levels
+  const uint32_t nblk = num_blocks(n);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (uint32_t i = lane; i < 1024; i += kWave) s_ins[i] = 0;
+  __syncthreads();
+  enum : uint32_t { ST_DONE = 0, ST_RUN = 1, ST_UNCERTAIN = 2, ST_MORE = 3 };
+
+  for (uint32_t b = 0; b < nblk; b++) {
+    const uint32_t bs = block_start(b), be = block_end(b, n);  // 1-based, inclusive
+    uint32_t *tok = B.bufA + (size_t)s * B.nvp + (bs - 1);
+    uint32_t ntok = 0, x = bs - 1;  // x: 0-based stream position
+    while (x + 1 <= be) {
+      const uint32_t c0 = x;
+      const uint32_t p = c0 + lane;  // this lane's position (0-based)
+      const bool valid = p + 1 <= be;
+      // ---- phase 1: the list of position p against the bitmap
+      uint32_t dd[K / 2], nb[K / 8];
+      {
+        const uint32_t pc = valid ? p : c0;
+        if (K == 8) {
+          const uint4 a = *(const uint4 *)(dg + (size_t)pc * 4);
+          dd[0] = a.x, dd[1] = a.y, dd[2] = a.z, dd[3] = a.w;
+          nb[0] = ng[pc];
+        } else {
+          const uint4 a = *(const uint4 *)(dg + (size_t)pc * 8), c = *(const uint4 *)(dg + (size_t)pc * 8 + 4);
+          const uint2 e = *(const uint2 *)(ng + (size_t)pc * 2);
+          dd[0] = a.x, dd[1] = a.y, dd[2] = a.z, dd[3] = a.w;
+          dd[4 % (K / 2)] = c.x, dd[5 % (K / 2)] = c.y, dd[6 % (K / 2)] = c.z, dd[7 % (K / 2)] = c.w;
+          nb[0] = e.x, nb[1 % (K / 8)] = e.y;
+        }
+      }
+      const uint32_t litv = V[valid ? p : c0];
+      // LD:1362-1398 over the list, for the lanes in `act`; candidates at or beyond `final_below` are not final yet
+      uint32_t best, bd, st, depth, lastd;
+      auto eval = [&](bool act, uint32_t final_below) {
+        best = 0, bd = 0, depth = max_chain, lastd = 0;
+        st = act ? ST_RUN : ST_DONE;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const uint32_t e = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+          const bool run = st == ST_RUN;
+          const bool end = e == 0xFFFFu;  // (an entry is never 0xFFFF otherwise: a distance of 32768 has no successor)
+          const uint32_t dist = (e & 0x7FFFu) + 1;
+          const uint32_t q = p - dist;  // (no dictionary: q >= 0 for every entry phase A wrote)
+          const bool early = run & !end & (q >= final_below);
+          const bool look = run & !end & !early;
+          const uint32_t w = look ? s_ins[(q >> 5) & 1023u] : 0u;
+          const bool ins = look & (((w >> (q & 31)) & 1u) != 0);
+          const uint32_t L = ((nb[k >> 3] >> (4 * (k & 7))) & 15u) + 3;
+          const bool better = ins & (L > best);  // LD:1385
+          bd = better ? dist : bd;
+          best = better ? L : best;
+          depth -= ins ? 1u : 0u;
+          lastd = look ? dist : lastd;
+          st = run ? (end ? (uint32_t)ST_DONE : (early ? (uint32_t)ST_UNCERTAIN : ((ins & ((best >= nice) | (depth == 0))) ? (uint32_t)ST_DONE : (uint32_t)ST_RUN))) : st;
+        }
+        // the list is used up and the walk still runs: more candidates only if the chain goes on (bit 15 of the last entry)
+        const bool more = (dd[K / 2 - 1] >> 31) != 0;
+        st = st == ST_RUN ? (more ? (uint32_t)ST_MORE : (uint32_t)ST_DONE) : st;
+      };
+      eval(valid && p + 3 <= be /* LD:1349 */, c0);
+      const uint32_t best1 = best, bd1 = bd, st1 = st;
+      // ---- phase 2: the walk over these 64 positions.  The scalar unit only hops from token to token over the lanes
+      // whose result is final (one v_readlane + add a token); what each of those tokens needs done -- forming it,
+      // storing it, its bits of the bitmap -- is done by the lanes, for all of them at once.  A lane whose result is not
+      // final stops the hop: it is resolved on its own (wave-uniform code), then the hopping goes on behind it.
+      const uint32_t limit = be - c0 < kWave ? be - c0 : kWave;  // lanes with a position inside the block
+      const bool m1 = (best1 > 3) | ((best1 == 3) & (bd1 < 4096));  // LD:1402-1404
+      const uint32_t len1 = m1 ? best1 : 1u;
+      uint32_t maxlen_l = be - p;  // (this lane's position)
+      maxlen_l = maxlen_l > kMaxMatch ? kMaxMatch : maxlen_l;
+      // not final: uncertain, needs more candidates, or a length of "18 or more"
+#if defined(LDH_G2_STOP) && LDH_G2_STOP >= 2  // timing experiments only (results are wrong): every lane counts as final
+      const unsigned long long special = 0;
+#else
+      const unsigned long long special =
+          ballot64(valid & ((st1 != ST_DONE) | (m1 & (best1 >= kCandLenCap) & (maxlen_l > kCandLenCap))));
+#endif
+      const uint32_t tok1 = m1 ? tok_match(best1, bd1) : litv;
+      uint32_t cur = 0, nt = 0;
+      while (cur < limit) {
+        unsigned long long vis = 0;
+        uint32_t k = cur;
+        while (k < limit && !((special >> k) & 1ull)) {
+          vis |= 1ull << k;
+          k += (uint32_t)__builtin_amdgcn_readlane((int)len1, (int)k);
+        }
+        if (vis) {  // (uniform)
+          const bool isv = ((vis >> lane) & 1ull) != 0;
+          if (isv) tok[ntok + nt + (uint32_t)__popcll(vis & below)] = tok1;
+          nt += (uint32_t)__popcll(vis);
+          // the bitmap over [c0 + cur, c0 + k): a token's first position always, the others of a match of at most
+          // max_insert_length bytes too (LD:1452-1462); M = those bits relative to c0 (a short match near lane 63
+          // reaches a few bits beyond 64)
+          unsigned long long mlo = vis, mhi = 0;
+#pragma unroll
+          for (uint32_t j = 1; j < 6; j++) {
+            if (j < max_insert) {  // (uniform)
+              const unsigned long long bj = ballot64(isv & m1 & (len1 <= max_insert) & (len1 > j));
+              mlo |= bj << j;
+              mhi |= bj >> (64 - j);
+            }
+          }
+          const uint32_t first = c0 + cur, last = c0 + k - 1, wi = (first >> 5) + lane;
+          if (wi <= (last >> 5)) {
+            const uint32_t lo = first > wi * 32 ? first - wi * 32 : 0u;
+            const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
+            const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+            const int32_t rel0 = (int32_t)(wi * 32) - (int32_t)c0;  // bit 0 of this word, relative to c0: -31 ..
+            uint32_t val;
+            if (rel0 < 0)
+              val = (uint32_t)(mlo << (uint32_t)(-rel0));
+            else if (rel0 < 64)
+              val = (uint32_t)(mlo >> (uint32_t)rel0) | (rel0 > 32 ? (uint32_t)(mhi << (uint32_t)(64 - rel0)) : 0u);
+            else
+              val = rel0 < 128 ? (uint32_t)(mhi >> (uint32_t)(rel0 - 64)) : 0u;
+            const uint32_t slot = wi & 1023u;
+            s_ins[slot] = (s_ins[slot] & ~mask) | (val & mask);
+          }
+          lds_order();
+          cur = k;
+          if (cur >= limit) break;
+        }
+        // ---- the lane at `cur` is not final: resolve it now that everything before it is
+        const uint32_t px = c0 + cur;  // the position the walk is at
+        uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)best1, (int)cur);
+        uint32_t td = (uint32_t)__builtin_amdgcn_readlane((int)bd1, (int)cur);
+        const uint32_t ts = (uint32_t)__builtin_amdgcn_readlane((int)st1, (int)cur);
+        uint32_t maxlen = be - px;
+        maxlen = maxlen > kMaxMatch ? kMaxMatch : maxlen;
+        if (ts != ST_DONE) {
+          // again, now that everything before px is final -- this time with a lane per candidate: entry k of the
+          // position's list goes to lane k (evaluating the list once more in the one lane that holds it, entry after
+          // entry, cost 160 instructions a time and half of the kernel), and when the chain goes on beyond the list,
+          // the list of its last candidate holds the next K candidates (distances from that candidate).  Lengths:
+          // the position's own list has them (nibbles); candidates of later trips are compared byte by byte.  A trip
+          // beyond the first is two dependent fetches (the list, then the candidates' bytes); the list of the NEXT
+          // trip is fetched as soon as this trip's last candidate is known, beside the bytes.
+          const bool have = lane < (uint32_t)K;
+          uint32_t e = 0xFFFFu, Ln = 0;
+          {
+            uint32_t v = 0, nw = 0;
+#pragma unroll
+            for (int i = 0; i < K / 2; i++) {
+              const uint32_t di = (uint32_t)__builtin_amdgcn_readlane((int)dd[i], (int)cur);
+              v = (lane >> 1) == (uint32_t)i ? di : v;
+            }
+#pragma unroll
+            for (int i = 0; i < K / 8; i++) {
+              const uint32_t ni = (uint32_t)__builtin_amdgcn_readlane((int)nb[i], (int)cur);
+              nw = (lane >> 3) == (uint32_t)i ? ni : nw;
+            }
+            if (have) e = (v >> (16 * (lane & 1))) & 0xFFFFu;
+            Ln = ((nw >> (4 * (lane & 7))) & 15u) + 3;
+            Ln = Ln > maxlen ? maxlen : Ln;
+          }
+          tb = 0, td = 0;
+          uint32_t dleft = max_chain, cl = px;
+          uint32_t my0 = 0, my1 = 0, my2 = 0, my3 = 0;
+          bool first_trip = true;
+          uint32_t e_next = 0xFFFFu;
+          for (;;) {
+            const uint32_t e_last = (uint32_t)__builtin_amdgcn_readlane((int)e, K - 1);
+            const bool more = e_last != 0xFFFFu && (e_last >> 15) != 0;
+            if (more) {  // (uniform) the next trip's list; harmless if this trip ends the walk
+              const uint32_t cl_next = cl - ((e_last & 0x7FFFu) + 1);
+              if (have) e_next = (uint32_t)dg16[(size_t)cl_next * K + lane];
+            }
+            const uint32_t q = cl - ((e & 0x7FFFu) + 1);
+            const bool ok = have && e != 0xFFFFu && px - q <= kWindow;  // LD:1365 against px's window
+            const unsigned long long notok = ~ballot64(ok);
+            const uint32_t first_bad = (uint32_t)__builtin_ctzll(notok);  // (<= K: lanes K.. are never ok)
+            const bool in_chain = lane < first_bad;
+            const bool ins = in_chain && ((s_ins[(q >> 5) & 1023u] >> (q & 31)) & 1u);
+            const unsigned long long insm = ballot64(ins);
+            const bool sel = ins && (uint32_t)__popcll(insm & below) < dleft;  // LD:1362
+            uint32_t L = 0;
+            if (first_trip) {  // (uniform)
+              L = sel ? Ln : 0u;
+            } else if (sel) {
+              const uint32_t x0 = gld4(V, q + 3) ^ my0, x1 = gld4(V, q + 7) ^ my1, x2 = gld4(V, q + 11) ^ my2, x3 = gld4(V, q + 15) ^ my3;
+              L = 3 + (x0 ? (uint32_t)__builtin_ctz(x0) >> 3
+                          : (x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
+                                : (x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : (x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u))));
+              L = L > maxlen ? maxlen : L;
+              L = L > kCandLenCap ? kCandLenCap : L;
+            }
+            const unsigned long long selm = ballot64(sel);
+            const unsigned long long nicem = ballot64(sel && L >= nice);
+            const uint32_t first_nice = nicem ? (uint32_t)__builtin_ctzll(nicem) : 64u;
+            unsigned long long m = selm & (first_nice >= 63 ? ~0ull : ((2ull << first_nice) - 1ull));
+            while (m) {  // (a handful of lanes: nearest first, LD:1385 strict)
+              const uint32_t j = (uint32_t)__builtin_ctzll(m);
+              m &= m - 1;
+              const uint32_t Lj = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)j);
+              if (Lj > tb) {
+                tb = Lj;
+                td = px - (uint32_t)__builtin_amdgcn_readlane((int)q, (int)j);
+              }
+            }
+            dleft -= (uint32_t)__popcll(selm);
+            if (nicem || first_bad < (uint32_t)K || dleft == 0 || !more) break;
+#if defined(LDH_G2_STOP) && LDH_G2_STOP >= 1  // timing experiments only (results are wrong): no trip beyond the first
+            break;
+#endif
+            cl = (uint32_t)__builtin_amdgcn_readlane((int)q, K - 1);
+            e = e_next;
+            if (first_trip) {
+              my0 = gld4(V, px + 3), my1 = gld4(V, px + 7), my2 = gld4(V, px + 11), my3 = gld4(V, px + 15);
+              first_trip = false;
+            }
+          }
+        }
+        // a length of 18 is "18 or more": the true length from the bytes, by the whole wave (LD:1371-1383)
+        if (tb >= kCandLenCap && maxlen > kCandLenCap) {
+          const uint32_t cj = px - td;
+          const uint32_t off = 16 + 4 * lane;  // (16 + 4 * 63 > 258: some lane always ends the comparison)
+          uint32_t y = 1;
+          if (off < maxlen) y = gld4(V, cj + off) ^ gld4(V, px + off);
+          const unsigned long long mism = ballot64(y != 0);
+          const uint32_t f = (uint32_t)__builtin_ctzll(mism);
+          const uint32_t yf = (uint32_t)__builtin_amdgcn_readlane((int)y, (int)f);
+          uint32_t Lj = 16 + 4 * f;
+          if (Lj < maxlen) Lj += (uint32_t)__builtin_ctz(yf) >> 3;  // (a lane at or beyond maxlen holds y = 1: + 0)
+          tb = Lj > maxlen ? maxlen : Lj;
+        }
+        // ---- the token, and which of its positions enter the chains
+        uint32_t len = 1, t;
+        bool interior_on = true;
+        if (tb > 3 || (tb == 3 && td < 4096)) {
+          t = tok_match(tb, td);
+          len = tb;
+          interior_on = tb <= max_insert;  // LD:1454
+        } else {
+          t = (uint32_t)__builtin_amdgcn_readlane((int)litv, (int)cur);
+        }
+        if (lane == 0) tok[ntok + nt] = t;
+        nt++;
+        {
+          const uint32_t first = px, last = px + len - 1, wi = (first >> 5) + lane;
+          if (wi <= (last >> 5)) {
+            const uint32_t lo = first > wi * 32 ? first - wi * 32 : 0u;
+            const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
+            const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+            const uint32_t val = interior_on ? mask : (lane == 0 ? 1u << (first & 31) : 0u);
+            const uint32_t slot = wi & 1023u;
+            s_ins[slot] = (s_ins[slot] & ~mask) | val;
+          }
+        }
+        lds_order();
+        cur += len;
+      }
+      ntok += nt;
+      x = c0 + cur;
+    }
+    if (lane == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;
+  }
+}
+
 __global__ void k_tokens_literal(Batch B) {
   const uint32_t s = blockIdx.x;
   const uint32_t n = stream_len(B, s), D = B.dlen;

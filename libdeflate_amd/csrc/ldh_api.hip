@@ -282,8 +282,17 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   const uint32_t max_blocks = num_blocks((uint32_t)max_in_len);
 
   const bool greedy = need_lz && !level_cfg(level).lazy;  // levels 1-3
-  // lazy levels, streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS, any length)
-  const bool seg_links = need_lz && !greedy && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds;
+  // level 1 without a dictionary: candidate lists for every position (k_cand_lists), then one wavefront per stream
+  // that takes 64 positions a round (k_lz_greedy2); levels 2-3 and batches with a dictionary: k_lz_greedy on the sorted array
+  static const bool greedy_v1 = getenv("LDH_GREEDY_V1") != nullptr;
+  // (level 2, whose walk wants 8 inserted candidates, measured slower this way than on the sorted array: LDH_GREEDY2_MAX=2
+  // turns it on for that level too, with lists of 16)
+  static const int greedy2_max = getenv("LDH_GREEDY2_MAX") ? atoi(getenv("LDH_GREEDY2_MAX")) : 1;
+  const bool greedy2 = greedy && level <= greedy2_max && level <= 2 && vd == 0 && !greedy_v1;
+  const int candK = level == 1 ? 8 : 16;
+  const bool want_links = need_lz && (!greedy || greedy2);  // prevd[]: the lazy levels' search and the candidate lists
+  // streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS, any length)
+  const bool seg_links = want_links && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds;
   // (a workgroup takes a run of consecutive segments: whole streams when there are streams enough to fill the
   // chip -- up to 64 segments, 2 MiB -- else runs of kSegRun, whose first segment is sorted twice)
   const uint32_t seg_max = (uint32_t)(((size_t)vd + max_in_len + kSegG - 1) / kSegG);
@@ -291,7 +300,9 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   const uint32_t seg_runs = (seg_max + seg_run_len - 1) / seg_run_len;
   // the rest (greedy levels, short streams, V alone for level 0 / huffman_only): k_sort_links, in LDS when V fits there
   const bool sort_in_lds = (size_t)nvp + kVPad <= kSortLdsMaxV;
-  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + (greedy ? 24ull : 8ull) * nvp + (size_t)max_blocks * sizeof(BlockInfo) + 4;
+  const size_t cand_bytes = greedy2 ? cand_stream_bytes(nvp, candK) : 0;
+  const size_t per_stream = (size_t)(nvp + kVPad) + 2ull * nvp + ((greedy && !greedy2) ? 24ull : 8ull) * nvp + cand_bytes +
+                            (size_t)max_blocks * sizeof(BlockInfo) + 4;
   size_t chunk = std::max<size_t>(1, workspace_budget() / per_stream);
   if (chunk > count) chunk = count;
 
@@ -300,7 +311,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   if (int rc = ensure(cx.bufA, chunk * 4ull * nvp + 64)) return rc;
   if (int rc = ensure(cx.bufB, chunk * 4ull * nvp + 64)) return rc;
   if (greedy)
-    if (int rc = ensure(cx.bufC, chunk * 16ull * nvp + 64)) return rc;
+    if (int rc = ensure(cx.bufC, chunk * (greedy2 ? cand_bytes : 16ull * nvp) + 64)) return rc;
   if (int rc = ensure(cx.blocks, chunk * (size_t)max_blocks * sizeof(BlockInfo))) return rc;
   if (int rc = ensure(cx.adler, chunk * 4 + 64)) return rc;
 
@@ -314,6 +325,8 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
                           (const void *)k_match_lazy<false, kRefillMinDeep, kMatchThreads>,
                           (const void *)k_match_lazy<true, kRefillMinDeep, kMatchThreads>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
+    for (const void *f : {(const void *)k_cand_lists<8, kCandThreads>, (const void *)k_cand_lists<16, kCandThreads>})
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCandLdsBytes));
     cx.attr_done = true;
   }
 
@@ -337,7 +350,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     B.bufA = (uint32_t *)cx.bufA.p;
     B.bufB = (uint32_t *)cx.bufB.p;
     B.bufC = greedy ? (uint32_t *)cx.bufC.p : nullptr;
-    B.want_rank = greedy ? 1u : 0u;
+    B.want_rank = (greedy && !greedy2) ? 1u : 0u;
     B.sort_lds = sort_in_lds ? ((nvp + kVPad + 15) & ~15u) : 0u;
     B.need_lz = need_lz ? 1u : 0u;
     B.blocks = (BlockInfo *)cx.blocks.p;
@@ -401,6 +414,21 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
           LAUNCH("k_parse_lazy", k_parse_lazy<kParseThreadsNarrow>, c * max_blocks, kParseThreadsNarrow, 0, B);
         else
           LAUNCH("k_parse_lazy", k_parse_lazy<kParseThreads>, c * max_blocks, kParseThreads, 0, B);
+      } else if (greedy2) {
+        const uint32_t ctiles = (uint32_t)((max_in_len + kCandTile - 1) / kCandTile);
+        if (ctiles) {
+          if (max_in_len <= kMatchNarrowMaxV) {  // short streams: one tile is the whole stream, LDS sized to the longest
+            const uint32_t cap = (uint32_t)round_up(max_in_len + 288 + 16, 16);
+            const uint32_t lds = cap + 2 * (uint32_t)(max_in_len + 8);
+            if (candK == 8) LAUNCH("k_cand_lists", (k_cand_lists<8, kCandThreadsNarrow>), c * ctiles, kCandThreadsNarrow, lds, B, ctiles, cap);
+            else LAUNCH("k_cand_lists", (k_cand_lists<16, kCandThreadsNarrow>), c * ctiles, kCandThreadsNarrow, lds, B, ctiles, cap);
+          } else {
+            if (candK == 8) LAUNCH("k_cand_lists", (k_cand_lists<8, kCandThreads>), c * ctiles, kCandThreads, kCandLdsBytes, B, ctiles, kCandByteCap);
+            else LAUNCH("k_cand_lists", (k_cand_lists<16, kCandThreads>), c * ctiles, kCandThreads, kCandLdsBytes, B, ctiles, kCandByteCap);
+          }
+        }
+        if (candK == 8) LAUNCH("k_lz_greedy", k_lz_greedy2<8>, c, kWave, 0, B);
+        else LAUNCH("k_lz_greedy", k_lz_greedy2<16>, c, kWave, 0, B);
       } else {
         LAUNCH("k_lz_greedy", k_lz_greedy, c, kWave, 0, B);
       }
