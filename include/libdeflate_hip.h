@@ -79,6 +79,19 @@ int ldh_use_context(int index);
 /* first[0..parts]: part p takes streams [first[p], first[p+1]); pure host arithmetic. */
 int ldh_partition_by_bytes(const uint64_t *in_off, size_t count, int parts, size_t *first);
 
+/* ---- caller-pinned host memory (no reference counterpart) -------------------------------------------------
+ * ldh_compress_batch / ldh_decompress_batch take ordinary pageable memory and stage it through pinned buffers of
+ * their own (a gather before the copy in, a scatter after the copy out: host memcpy work that costs as much as the
+ * PCIe transfers).  Inputs that lie inside a range pinned here are copied to the device straight from the caller's
+ * memory, and results into output slots inside such a range straight from the device (rows as wide as the piece's
+ * longest result: bytes of a slot beyond out_len[s], and slots of streams whose status is not 0, may then hold
+ * anything).  ldh_host_register pins memory the caller owns (hipHostRegister); ldh_host_alloc returns pinned memory
+ * (hipHostMalloc) to be released with ldh_host_free.  The small per-stream arrays need no pinning. */
+int ldh_host_register(void *p, size_t bytes);
+int ldh_host_unregister(void *p);
+void *ldh_host_alloc(size_t bytes);
+void ldh_host_free(void *p);
+
 /* Largest output CompressDeflate/CompressZlib can produce for n input bytes at any
  * level/strategy; also the required out_stride granularity (multiple of 16). */
 size_t ldh_compress_bound(size_t n);

@@ -52,6 +52,10 @@ _SIGS = {
     "ldh_use_context": (C.c_int, [C.c_int]),
     "ldh_partition_by_bytes": (C.c_int, [u64p, sz, C.c_int, C.c_void_p]),
     "ldh_compress_bound": (sz, [sz]),
+    "ldh_host_register": (C.c_int, [C.c_void_p, sz]),
+    "ldh_host_unregister": (C.c_int, [C.c_void_p]),
+    "ldh_host_alloc": (C.c_void_p, [sz]),
+    "ldh_host_free": (None, [C.c_void_p]),
     "ldh_dict_create": (C.c_void_p, [u8p, sz]),
     "ldh_dict_free": (None, [C.c_void_p]),
     "ldh_dict_adler32": (C.c_uint32, [C.c_void_p]),

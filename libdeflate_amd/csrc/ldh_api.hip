@@ -6,6 +6,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
+#include <chrono>
+#include <pthread.h>
+#include <sched.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +99,7 @@ struct Ctx {
   uint32_t *noalloc = nullptr;  // this device's copy of `scratch`
   hipEvent_t ev_noalloc = nullptr;  // end of this context's last ldh_decompress_batch_dev_noalloc (see g_scratch_last)
   bool attr_done = false;
+  std::vector<int> near_cpus;   // the CPUs of this GPU's NUMA node (threads the library starts for this context run there)
   // last compress batch (for ldh_debug_fetch)
   Batch last{};
   bool have_last = false;
@@ -260,6 +265,98 @@ const ldh::CodecTables *codec_on(Ctx &cx, const ldh_codec *cc) {
   c->dev.push_back({cx.device, p});
   return p;
 }
+
+// ---- caller-pinned host memory, thread placement, host-side trace --------------------------------------------
+// Ranges the caller has pinned through ldh_host_register / ldh_host_alloc.  A host-pointer batch call whose inputs (or
+// outputs) lie inside one of them copies straight between the caller's memory and the device: no gather into the
+// library's pinned staging, no scatter out of it.
+struct HostRange {
+  uintptr_t lo, hi;
+  bool owned;  // hipHostMalloc'ed by ldh_host_alloc (else hipHostRegister'ed)
+};
+std::mutex g_host_mu;
+std::vector<HostRange> g_host_ranges;
+bool host_pinned(const void *p, size_t bytes) {
+  if (!bytes) return true;
+  const uintptr_t a = (uintptr_t)p;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  for (const HostRange &r : g_host_ranges)
+    if (a >= r.lo && a + bytes <= r.hi) return true;
+  return false;
+}
+
+// The CPUs next to a GPU ("pin threads and buffers per NUMA node"): the PCI device's numa_node in sysfs and
+// that node's cpulist.  Best effort: no sysfs entry, node -1 or LDH_NO_AFFINITY=1 leave the threads where they are.
+std::vector<int> cpus_near_device(int device) {
+  std::vector<int> cpus;
+  if (getenv("LDH_NO_AFFINITY")) return cpus;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return cpus;
+  for (char *c = bus; *c; c++) *c = (char)tolower(*c);
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE *f = fopen(path, "r");
+  int node = -1;
+  if (f) {
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+  }
+  if (node < 0) return cpus;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  if (!f) return cpus;
+  char line[4096] = {0};
+  if (fgets(line, sizeof(line), f)) {
+    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+      int a = 0, b = 0;
+      const int k = sscanf(tok, "%d-%d", &a, &b);
+      if (k == 1) b = a;
+      if (k >= 1)
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) cpus.push_back(c);
+    }
+  }
+  fclose(f);
+  // (never widen what the process was given: cgroups / taskset of the caller stay in force)
+  cpu_set_t cur;
+  CPU_ZERO(&cur);
+  if (sched_getaffinity(0, sizeof(cur), &cur) == 0) {
+    std::vector<int> both;
+    for (int c : cpus)
+      if (CPU_ISSET(c, &cur)) both.push_back(c);
+    cpus.swap(both);
+  }
+  return cpus;
+}
+void bind_this_thread(const std::vector<int> &cpus) {
+  if (cpus.empty()) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : cpus) CPU_SET(c, &set);
+  pthread_setaffinity_np(pthread_self(), sizeof(set), &set);  // (failure: the thread stays where it is)
+}
+thread_local const std::vector<int> *t_near = nullptr;  // the calling context's CPU list, for the copy threads it starts
+
+// LDH_HOST_TRACE=1: host-clock milliseconds per stage of the host-pointer pipelines, printed to stderr per call
+struct HostTrace {
+  bool on = getenv("LDH_HOST_TRACE") != nullptr;
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now(), start = last;
+  void lap(int k) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    t[k] += std::chrono::duration<double, std::milli>(now - last).count();
+    last = now;
+  }
+  void report(const char *what, size_t pieces, bool din, bool dout) {
+    if (!on) return;
+    const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count();
+    fprintf(stderr,
+            "[ldh host trace] %s: %zu piece(s), input %s, output %s: total %.2f ms = gather/enqueue-in %.2f + enqueue kernels %.2f + "
+            "wait kernels %.2f + wait copy-out %.2f + scatter %.2f + other %.2f\n",
+            what, pieces, din ? "direct" : "staged", dout ? "direct" : "staged", tot, t[0], t[1], t[2], t[3], t[4],
+            tot - t[0] - t[1] - t[2] - t[3] - t[4]);
+  }
+};
 
 // ---- compress ---------------------------------------------------------------
 int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
@@ -543,9 +640,12 @@ size_t piece_bytes() {
   const size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : 65536;
   return std::max<size_t>(kb, 1) << 10;
 }
-// k_inflate runs one wavefront per stream and a stream takes milliseconds however few there are,
-// so decompression wants thousands of streams per piece
-size_t inflate_piece_bytes() { return 4 * piece_bytes(); }
+// A stream takes milliseconds to inflate however few there are, so decompression wants many streams per piece: 128 MiB
+// of results (1024 streams of 128 KiB: k_inflate_wide's range; 256 MiB and one wavefront per stream before round 3)
+size_t inflate_piece_bytes() {
+  static const size_t mult = getenv("LDH_INFLATE_PIECE_MULT") ? (size_t)atoi(getenv("LDH_INFLATE_PIECE_MULT")) : 2;
+  return std::max<size_t>(mult, 1) * piece_bytes();
+}
 int ensure_pinned(PinBuf &b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
@@ -626,7 +726,12 @@ void par_ranges(size_t n, size_t bytes, F f) {
   }
   const size_t per = (n + T - 1) / T;
   std::vector<std::thread> th;
-  for (size_t lo = per; lo < n; lo += per) th.emplace_back([=] { f(lo, std::min(n, lo + per)); });
+  const std::vector<int> *near = t_near;
+  for (size_t lo = per; lo < n; lo += per)
+    th.emplace_back([=] {
+      if (near) bind_this_thread(*near);
+      f(lo, std::min(n, lo + per));
+    });
   f((size_t)0, std::min(n, per));
   for (auto &t : th) t.join();
 }
@@ -674,6 +779,7 @@ Ctx *ctx_create(int device, int *rc) {
     return nullptr;
   }
   c->noalloc = (uint32_t *)sym;
+  c->near_cpus = cpus_near_device(device);
   {
     std::lock_guard<std::mutex> sl(g_scratch_mu);
     g_scratch_last.reserve(64);
@@ -920,6 +1026,64 @@ void ldh_dict_free(ldh_dict *d) {
 uint32_t ldh_dict_adler32(const ldh_dict *d) { return d ? d->adler : 0; }
 size_t ldh_dict_len(const ldh_dict *d) { return d ? d->bytes.size() : 0; }
 
+// ---- caller-pinned host memory -----------------------------------------------------
+int ldh_host_register(void *p, size_t bytes) {
+  Ctx *c = current();
+  if (!c) return fail(LDH_E_NOT_INIT, "ldh_init() has not been called");
+  if (!p || !bytes) return fail(LDH_E_ARG, "ldh_host_register: empty range");
+  HIPCHK(hipSetDevice(c->device));
+  // pages are what gets pinned: the whole pages the range touches (hipHostRegister wants page granularity)
+  const uintptr_t pg = 4096, lo = (uintptr_t)p & ~(pg - 1), hi = ((uintptr_t)p + bytes + pg - 1) & ~(pg - 1);
+  const hipError_t e = hipHostRegister((void *)lo, hi - lo, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(LDH_E_HIP, "hipHostRegister(%p, %zu): %s", (void *)lo, (size_t)(hi - lo), hipGetErrorString(e));
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  g_host_ranges.push_back({(uintptr_t)p, (uintptr_t)p + bytes, false});
+  return 0;
+}
+int ldh_host_unregister(void *p) {
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t i = 0;
+    for (; i < g_host_ranges.size(); i++)
+      if (g_host_ranges[i].lo == (uintptr_t)p && !g_host_ranges[i].owned) break;
+    if (i == g_host_ranges.size()) return fail(LDH_E_ARG, "ldh_host_unregister: %p was not registered", p);
+    g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+  }
+  HIPCHK(hipHostUnregister((void *)((uintptr_t)p & ~(uintptr_t)4095)));
+  return 0;
+}
+void *ldh_host_alloc(size_t bytes) {
+  Ctx *c = current();
+  if (!c) {
+    fail(LDH_E_NOT_INIT, "ldh_init() has not been called");
+    return nullptr;
+  }
+  void *p = nullptr;
+  g_allocs++;
+  if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    fail(LDH_E_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  g_host_ranges.push_back({(uintptr_t)p, (uintptr_t)p + (bytes ? bytes : 1), true});
+  return p;
+}
+void ldh_host_free(void *p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (size_t i = 0; i < g_host_ranges.size(); i++)
+      if (g_host_ranges[i].lo == (uintptr_t)p && g_host_ranges[i].owned) {
+        g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+        break;
+      }
+  }
+  hipHostFree(p);
+}
+
 // ---- batched, device pointers -------------------------------------------------
 int ldh_compress_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t count, size_t max_in_len,
                            int fmt, int level, int strategy, const ldh_dict *dict, uint8_t *d_out,
@@ -1036,6 +1200,12 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   if (int rc = pipeline_init(cx)) return rc;
   DrainGuard drain;
+  t_near = &cx.near_cpus;
+  HostTrace tr;
+  // caller-pinned memory (ldh_host_register / ldh_host_alloc) is copied from and to directly
+  const bool pin_in = host_pinned(in_base + in_off[0], in_off[count] - in_off[0]);
+  const bool pin_out = host_pinned(out_base, count * out_stride);
+  size_t npieces = 0;
   // group streams by resolved level (LD:1782-1790) and by size class so that the
   // per-stream workspace (sized by the longest stream of a launch) is not wasted
   struct Group {
@@ -1069,35 +1239,55 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
     struct Piece {
       size_t first, last;
       uint64_t bytes;
+      bool contiguous;  // streams idx[first] .. idx[last-1] are neighbours in the caller's batch
     };
     std::vector<Piece> pieces;
     const size_t piece = piece_bytes();
     for (size_t i = 0; i < g.idx.size();) {
-      Piece pc{i, i, 0};
+      Piece pc{i, i, 0, true};
       while (pc.last < g.idx.size() && (pc.last == pc.first || pc.bytes < piece)) {
         pc.bytes += in_off[g.idx[pc.last] + 1] - in_off[g.idx[pc.last]];
         pc.last++;
       }
+      pc.contiguous = g.idx[pc.last - 1] - g.idx[pc.first] + 1 == pc.last - pc.first;
       pieces.push_back(pc);
       i = pc.last;
     }
+    npieces += pieces.size();
     auto finish = [&](size_t k) -> int {  // results of piece k to the caller
       Slot &sl = cx.slot[k & 1];
       const Piece &pc = pieces[k];
       const size_t gc = pc.last - pc.first;
+      tr.lap(5);
       HIPCHK(hipEventSynchronize(sl.ev_done));
+      tr.lap(2);
       const uint32_t *lens = (const uint32_t *)sl.pin_small.p;
       const uint8_t *pads = (const uint8_t *)sl.pin_small.p + gc * 4;
       size_t w = 0;
       for (size_t i = 0; i < gc; i++) w = std::max<size_t>(w, lens[i]);
       w = std::min(round_up(w, 16), out_stride);
+      const size_t *idx = g.idx.data() + pc.first;
+      if (pin_out && pc.contiguous) {
+        // straight into the caller's slots: rows as wide as the piece's longest result
+        for (size_t i = 0; i < gc; i++) {
+          out_len[idx[i]] = lens[i];
+          pad_bits[idx[i]] = pads[i];
+        }
+        if (w) {
+          HIPCHK(hipMemcpy2DAsync(out_base + idx[0] * out_stride, out_stride, sl.d_out.p, out_stride, w, gc,
+                                  hipMemcpyDeviceToHost, cx.s_out));
+          HIPCHK(hipStreamSynchronize(cx.s_out));
+        }
+        tr.lap(3);
+        return 0;
+      }
       if (int rc = ensure_pinned(sl.pin_out, gc * w + 64)) return rc;
       if (w) {
         HIPCHK(hipMemcpy2DAsync(sl.pin_out.p, w, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, cx.s_out));
         HIPCHK(hipStreamSynchronize(cx.s_out));
       }
+      tr.lap(3);
       const uint8_t *rows = (const uint8_t *)sl.pin_out.p;
-      const size_t *idx = g.idx.data() + pc.first;
       par_ranges(gc, gc * w, [=](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
           out_len[idx[i]] = lens[i];
@@ -1105,14 +1295,18 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
           memcpy(out_base + idx[i] * out_stride, rows + i * w, lens[i]);
         }
       });
+      tr.lap(4);
       return 0;
     };
     for (size_t k = 0; k < pieces.size(); k++) {
       Slot &sl = cx.slot[k & 1];
       const Piece &pc = pieces[k];
       const size_t gc = pc.last - pc.first;
+      const bool direct_in = pin_in && pc.contiguous;
+      tr.lap(5);
       // (piece k-2, the last user of this slot, was finished before piece k-1 was enqueued)
-      if (int rc = ensure_pinned(sl.pin_in, pc.bytes + 64)) return rc;
+      if (!direct_in)
+        if (int rc = ensure_pinned(sl.pin_in, pc.bytes + 64)) return rc;
       if (int rc = ensure_pinned(sl.pin_off, (gc + 1) * 8)) return rc;
       if (int rc = ensure_pinned(sl.pin_small, gc * 5 + 64)) return rc;
       if (int rc = ensure(sl.d_in, pc.bytes + 64)) return rc;
@@ -1131,7 +1325,10 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
       }
       off[gc] = tot;
       const size_t *idx = g.idx.data() + pc.first;
-      if (idx[gc - 1] - idx[0] + 1 == gc) {
+      const uint8_t *src = (const uint8_t *)sl.pin_in.p;
+      if (direct_in) {
+        src = in_base + in_off[idx[0]];
+      } else if (pc.contiguous) {
         par_memcpy(sl.pin_in.p, in_base + in_off[idx[0]], tot);
       } else {
         uint8_t *dst = (uint8_t *)sl.pin_in.p;
@@ -1139,10 +1336,11 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
           for (size_t i = lo; i < hi; i++) memcpy(dst + off[i], in_base + in_off[idx[i]], off[i + 1] - off[i]);
         });
       }
-      if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, cx.s_in));
+      if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, src, tot, hipMemcpyHostToDevice, cx.s_in));
       HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, cx.s_in));
       HIPCHK(hipEventRecord(sl.ev_in, cx.s_in));
       HIPCHK(hipStreamWaitEvent(cx.stream, sl.ev_in, 0));
+      tr.lap(0);
       if (int rc = compress_dev_locked(cx, (const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, gc, max_len, fmt, lv,
                                        strategy, dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
                                        (uint8_t *)sl.d_a8.p))
@@ -1150,12 +1348,14 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
       HIPCHK(hipMemcpyAsync(sl.pin_small.p, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
       HIPCHK(hipMemcpyAsync((uint8_t *)sl.pin_small.p + gc * 4, sl.d_a8.p, gc, hipMemcpyDeviceToHost, cx.stream));
       HIPCHK(hipEventRecord(sl.ev_done, cx.stream));
+      tr.lap(1);
       if (k > 0)
         if (int rc = finish(k - 1)) return rc;
     }
     if (int rc = finish(pieces.size() - 1)) return rc;
   }
   drain.clean = true;
+  tr.report("ldh_compress_batch", npieces, pin_in, pin_out);
   return 0;
 }
 
@@ -1167,6 +1367,10 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   if (int rc = pipeline_init(cx)) return rc;
   DrainGuard drain;
+  t_near = &cx.near_cpus;
+  HostTrace tr;
+  const bool pin_in = host_pinned(in_base + in_off[0], in_off[count] - in_off[0]);
+  const bool pin_out = host_pinned(out_base, count * out_stride);
   struct Piece {
     size_t first, last;
   };
@@ -1182,7 +1386,9 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     Slot &sl = cx.slot[k % 3];
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first;
+    tr.lap(5);
     HIPCHK(hipEventSynchronize(sl.ev_done));
+    tr.lap(2);
     const uint32_t *lens = (const uint32_t *)sl.pin_small.p;
     const int32_t *st = (const int32_t *)((const uint8_t *)sl.pin_small.p + gc * 8);
     memcpy(out_len + pc.first, lens, gc * 4);
@@ -1194,6 +1400,17 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     w = std::min(round_up(w, 16), out_stride);
     sl.w = w;
     if (!w) return 0;
+    if (pin_out) {
+      // straight into the caller's slots (rows as wide as the piece's longest result; a slot whose stream failed, or
+      // the part of a slot beyond its own result, receives whatever the device buffer held there)
+      uint8_t *dst = out_base + pc.first * out_stride;
+      if (w == out_stride)
+        HIPCHK(hipMemcpyAsync(dst, sl.d_out.p, gc * w, hipMemcpyDeviceToHost, cx.s_out));
+      else
+        HIPCHK(hipMemcpy2DAsync(dst, out_stride, sl.d_out.p, out_stride, w, gc, hipMemcpyDeviceToHost, cx.s_out));
+      HIPCHK(hipEventRecord(sl.ev_out, cx.s_out));
+      return 0;
+    }
     if (int rc = ensure_pinned(sl.pin_out, gc * w + 64)) return rc;
     if (w == out_stride)
       HIPCHK(hipMemcpyAsync(sl.pin_out.p, sl.d_out.p, gc * w, hipMemcpyDeviceToHost, cx.s_out));
@@ -1207,7 +1424,10 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first, w = sl.w;
     if (!w) return 0;
+    tr.lap(5);
     HIPCHK(hipEventSynchronize(sl.ev_out));
+    tr.lap(3);
+    if (pin_out) return 0;
     const uint32_t *lens = (const uint32_t *)sl.pin_small.p;
     const int32_t *st = (const int32_t *)((const uint8_t *)sl.pin_small.p + gc * 8);
     const uint8_t *rows = (const uint8_t *)sl.pin_out.p;
@@ -1216,6 +1436,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
       for (size_t i = lo; i < hi; i++)
         if (st[i] == 0 && lens[i]) memcpy(dst + i * out_stride, rows + i * w, lens[i]);
     });
+    tr.lap(4);
     return 0;
   };
   for (size_t k = 0; k < pieces.size(); k++) {
@@ -1223,7 +1444,9 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first;
     const uint64_t base = in_off[pc.first], tot = in_off[pc.last] - base;
-    if (int rc = ensure_pinned(sl.pin_in, tot + 64)) return rc;
+    tr.lap(5);
+    if (!pin_in)
+      if (int rc = ensure_pinned(sl.pin_in, tot + 64)) return rc;
     if (int rc = ensure_pinned(sl.pin_off, (gc + 1) * 8)) return rc;
     if (int rc = ensure_pinned(sl.pin_small, gc * 12 + 64)) return rc;
     if (int rc = ensure(sl.d_in, tot + 64)) return rc;
@@ -1235,11 +1458,16 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     // offsets are re-based to start at 0 so that the device copy of the data is aligned
     uint64_t *off = (uint64_t *)sl.pin_off.p;
     for (size_t i = 0; i <= gc; i++) off[i] = in_off[pc.first + i] - base;
-    par_memcpy(sl.pin_in.p, in_base + base, tot);
-    if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, sl.pin_in.p, tot, hipMemcpyHostToDevice, cx.s_in));
+    const uint8_t *src = in_base + base;
+    if (!pin_in) {
+      par_memcpy(sl.pin_in.p, in_base + base, tot);
+      src = (const uint8_t *)sl.pin_in.p;
+    }
+    if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, src, tot, hipMemcpyHostToDevice, cx.s_in));
     HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, cx.s_in));
     HIPCHK(hipEventRecord(sl.ev_in, cx.s_in));
     HIPCHK(hipStreamWaitEvent(cx.stream, sl.ev_in, 0));
+    tr.lap(0);
     if (int rc = decompress_dev_locked(cx, (const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, nullptr, 0, gc, fmt,
                                        dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
                                        (uint32_t *)sl.d_a32a.p, (int32_t *)sl.d_a32b.p))
@@ -1249,6 +1477,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     HIPCHK(hipMemcpyAsync(small + gc * 4, sl.d_a32a.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
     HIPCHK(hipMemcpyAsync(small + gc * 8, sl.d_a32b.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
     HIPCHK(hipEventRecord(sl.ev_done, cx.stream));
+    tr.lap(1);
     if (k > 0)
       if (int rc = start_out(k - 1)) return rc;
     if (k > 1)
@@ -1260,6 +1489,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     if (int rc = scatter(np - 2)) return rc;
   if (int rc = scatter(np - 1)) return rc;
   drain.clean = true;
+  tr.report("ldh_decompress_batch", np, pin_in, pin_out);
   return 0;
 }
 
@@ -1285,6 +1515,7 @@ static int over_contexts(const uint64_t *in_off, size_t count, F f) {
   for (int p = 0; p < P; p++)
     th.emplace_back([&, p] {
       if (first[p + 1] == first[p]) return;
+      bind_this_thread(cxs[p]->near_cpus);  // this context's host thread runs beside its GPU
       rcs[p] = f(cxs[p], first[p], first[p + 1]);
       if (rcs[p]) errs[p] = g_err;  // (thread-local: hand it to the caller's thread)
     });

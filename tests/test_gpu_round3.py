@@ -124,3 +124,79 @@ def test_big_batch_greedy_levels(B, level):
     got = device_round_trip(B, streams, level, sample=sample)
     for i in sample:
         assert got[i] == o_compress(streams[i], level=level), (level, i, len(streams[i]))
+
+
+def test_host_batches_on_caller_pinned_memory(LD, B):
+    # buffers pinned by the caller (ldh_host_register / ldh_host_alloc) are copied from and to
+    # directly, no staging.  Same results as the staged path: a ragged batch in many pieces, raw and zlib + dictionary,
+    # with a failing stream (its slot may hold anything, its status must not), then the ranges are released again
+    import ctypes as C
+    from libdeflate_amd import _native as N
+    from libdeflate_amd import synth
+    N.init(0)
+    streams = [r.tobytes() for r in synth.text_streams(40, 50000, first_stream=900)]
+    streams[3] = streams[3][:17]
+    streams[11] = b""
+    streams[39] = streams[39][:40001]
+    dct = golden("dictionary32768.txt")
+    d = LD.CreateDictionary(dct, len(dct), o_adler32(dct))
+    lens = np.array([len(s) for s in streams], dtype=np.uint64)
+    off = np.zeros(len(streams) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    n, total = len(streams), int(off[-1])
+    stride = N.lib.ldh_compress_bound(50000)
+    p_in = N.lib.ldh_host_alloc(total + 16)
+    assert p_in
+    inp = np.ctypeslib.as_array(C.cast(p_in, C.POINTER(C.c_uint8)), shape=(total + 16,))
+    inp[:total] = np.frombuffer(b"".join(streams), dtype=np.uint8)
+    # (ldh_host_register pins memory the caller already owns; on hosts where the driver refuses that -- this pool's boxes:
+    # hipHostRegister returns "invalid argument" for any range -- it reports LDH_E_HIP and ldh_host_alloc is the way)
+    probe = np.zeros(1 << 16, dtype=np.uint8)
+    rc = N.lib.ldh_host_register(probe.ctypes.data, probe.nbytes)
+    assert rc in (0, -102)
+    registered = rc == 0
+    if registered:
+        N.check(N.lib.ldh_host_unregister(probe.ctypes.data))
+    p_out = N.lib.ldh_host_alloc(n * stride)
+    out = np.ctypeslib.as_array(C.cast(p_out, C.POINTER(C.c_uint8)), shape=(n * stride,))
+    try:
+        for fmt, dic, level in ((0, None, 5), (1, d, 7), (0, None, None)):
+            want = B.compress_batch(streams, fmt=fmt, level=level, dictionary=dic)   # staged path (ordinary memory)
+            out_len = np.zeros(n, dtype=np.uint32)
+            pad = np.zeros(n, dtype=np.uint8)
+            N.check(N.lib.ldh_compress_batch(p_in, off.ctypes.data, n, fmt, -1 if level is None else level, 0,
+                                             dic.handle() if dic else None, p_out, stride, out_len.ctypes.data,
+                                             pad.ctypes.data))
+            got = [(out[i * stride: i * stride + int(out_len[i])].tobytes(), int(pad[i])) for i in range(n)]
+            assert got == want, (fmt, level)
+            # inflate from pinned memory into pinned slots; stream 5 is cut short
+            comp = [c for c, _ in got]
+            comp[5] = comp[5][: len(comp[5]) // 2]
+            clens = np.array([len(c) for c in comp], dtype=np.uint64)
+            coff = np.zeros(n + 1, dtype=np.uint64)
+            np.cumsum(clens, out=coff[1:])
+            p_c = N.lib.ldh_host_alloc(int(coff[-1]) + 16)
+            cin = np.ctypeslib.as_array(C.cast(p_c, C.POINTER(C.c_uint8)), shape=(int(coff[-1]) + 16,))
+            cin[: int(coff[-1])] = np.frombuffer(b"".join(comp), dtype=np.uint8)
+            ostride = 50000 + 16
+            p_o = N.lib.ldh_host_alloc(n * ostride)
+            back = np.ctypeslib.as_array(C.cast(p_o, C.POINTER(C.c_uint8)), shape=(n * ostride,))
+            blen = np.zeros(n, dtype=np.uint32)
+            left = np.zeros(n, dtype=np.uint32)
+            st = np.zeros(n, dtype=np.int32)
+            N.check(N.lib.ldh_decompress_batch(p_c, coff.ctypes.data, n, fmt, dic.handle() if dic else None, p_o, ostride,
+                                               blen.ctypes.data, left.ctypes.data, st.ctypes.data))
+            ref = B.decompress_batch(comp, fmt=fmt, dictionary=dic, max_out=50000)
+            for i in range(n):
+                if ref[i][0] is None:
+                    assert int(st[i]) == ref[i][1], i
+                else:
+                    assert int(st[i]) == 0 and back[i * ostride: i * ostride + int(blen[i])].tobytes() == ref[i][0], i
+                    assert int(left[i]) == ref[i][1]
+            N.lib.ldh_host_free(p_c)
+            N.lib.ldh_host_free(p_o)
+    finally:
+        N.lib.ldh_host_free(p_out)
+        N.lib.ldh_host_free(p_in)
+    with pytest.raises(N.LdhError):
+        N.check(N.lib.ldh_host_unregister(probe.ctypes.data))    # not (or no longer) registered
