@@ -13,6 +13,7 @@
   local rc = Batch.CompressBuffers(in_ptr, off_ptr, n, fmt, configs, dictionary, out_ptr, out_stride, len_ptr, pad_ptr)
   local rc = Batch.DecompressBuffers(in_ptr, off_ptr, n, fmt, dictionary, out_ptr, out_stride, len_ptr, left_ptr, status_ptr)
   local buf  = Batch.Alloc(nbytes)               -- malloc'ed uint8_t*, freed by the garbage collector (ffi.gc)
+  local buf  = Batch.AllocPinned(nbytes)         -- page-locked (ldh_host_alloc): the *Buffers calls copy from / to it directly
   local need = Batch.CompressBound(maxlen)       -- out_stride for CompressBuffers
 
 The list forms build ONE Lua string (table.concat) and ONE ffi.new array for the results: both live on LuaJIT's
@@ -43,6 +44,10 @@ int ldh_print6_decode_batch(const uint8_t *in_base, const uint64_t *in_off, size
 ffi.cdef [[
 void *malloc(size_t size);
 void free(void *ptr);
+]]
+ffi.cdef [[
+void *ldh_host_alloc(size_t bytes);
+void ldh_host_free(void *p);
 ]]
 
 local Batch = {}
@@ -111,6 +116,14 @@ function Batch.Alloc(nbytes)
   local p = ffi.C.malloc(nbytes)
   if p == nil then error("LibDeflateBatch.Alloc: out of memory (" .. tostring(nbytes) .. " bytes)", 2) end
   return ffi.gc(ffi.cast("uint8_t *", p), ffi.C.free)
+end
+
+-- nbytes of page-locked host memory (ldh_host_alloc) as uint8_t*: the library copies between such a buffer and the GPU
+-- directly, without staging it through pinned buffers of its own (about a fifth faster at 2048 x 128 KiB)
+function Batch.AllocPinned(nbytes)
+  local p = C.ldh_host_alloc(nbytes)
+  if p == nil then error("LibDeflateBatch.AllocPinned: cannot pin " .. tostring(nbytes) .. " bytes", 2) end
+  return ffi.gc(ffi.cast("uint8_t *", p), C.ldh_host_free)
 end
 
 -- out_stride: a multiple of 16, at least Batch.CompressBound(longest stream); pad_ptr: uint8_t[n]

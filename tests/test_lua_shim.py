@@ -78,7 +78,7 @@ def test_batch_module_is_reachable_and_complete():
     src = open(os.path.join(LUA, "LibDeflateBatch.lua")).read()
     assert set(re.findall(r"^function Batch\.([A-Za-z0-9]+)", src, flags=re.M)) >= {
         "Compress", "Decompress", "Adler32", "EncodeForPrint", "DecodeForPrint", "CompressBuffers", "DecompressBuffers",
-        "Alloc", "CompressBound"}
+        "Alloc", "AllocPinned", "CompressBound"}
     assert re.search(r"^return Batch\s*$", src, flags=re.M)
     assert 'require("LibDeflate")' in src and 'package.loaded["LibDeflate.__hip"]' in src
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
