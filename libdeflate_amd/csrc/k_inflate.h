@@ -325,6 +325,12 @@ __device__ int decode_one(const LitTab &LT, const DistTab &DT, int lbits, int db
   return 0;
 }
 
+// a value the caller knows to be the same in every lane, moved to scalar registers
+__device__ inline uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); }
+__device__ inline uint64_t uni64(uint64_t x) {
+  return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x);
+}
+
 __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lane) {
   br_seek(R, bit_pos >> 3, lane);
   const uint32_t drop = (uint32_t)(bit_pos & 7);
@@ -356,22 +362,27 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     ext = O.dlen;
     O.dict_loaded = true;
   }
-  const uint64_t nbits = (uint64_t)R.nbytes * 8;
-  const uint64_t skip_bits = (uint64_t)R.skip * 8;
-  const uint32_t cap = (uint32_t)O.cap;
-  uint8_t *const out = O.out;
-  uint32_t op = (uint32_t)O.opos;  // output position (uniform)
-  uint64_t bp = R.consumed;        // bits consumed so far (uniform); current only while !have
+  // (The called copy gets its state through references: the compiler cannot tell that what it loads from them is
+  // wave-uniform and would keep positions, pointers and the loop's conditions in vector registers.  v_readfirstlane
+  // says so; in the inlined copy, where they are scalar already, it folds away.)
+  const uint32_t r_nbytes = uni(R.nbytes), r_skip = uni(R.skip);
+  const uint32_t *const r_base = (const uint32_t *)uni64((uint64_t)(uintptr_t)R.base);
+  const uint64_t nbits = (uint64_t)r_nbytes * 8;
+  const uint64_t skip_bits = (uint64_t)r_skip * 8;
+  const uint32_t cap = uni((uint32_t)O.cap);
+  // (a global, not a generic, pointer: loads and stores take the scalar base and a 32-bit lane offset as they are,
+  // without a 64-bit vector add per access, and do not count as LDS operations in the wait counters)
+  typedef __attribute__((address_space(1))) uint8_t *gbytes_t;
+  const gbytes_t out = (gbytes_t)uni64((uint64_t)(uintptr_t)O.out);
+  uint32_t op = uni((uint32_t)O.opos);  // output position (uniform)
+  uint64_t bp = uni64(R.consumed);      // bits consumed so far (uniform); current only while !have
   int64_t bp0 = 0;                 // bits consumed = bp0 + rel while the window is valid
   uint32_t rel = 0;                // bit offset of the current position in the window
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
   bool have = false;
   const unsigned long long le_mask = (2ull << lane) - 1ull;  // lanes 0..lane
-#ifndef LDH_INFLATE_LAZY_FENCE
-#define LDH_INFLATE_LAZY_FENCE 0  // measured: 11.3 ms per GiB against 11.0 with the fence every round; one 128 KiB string 5.05 against 4.81 ms
-#endif
-  constexpr bool kLazyFence = LDH_INFLATE_LAZY_FENCE != 0;
-  uint32_t safe = 0;  // see the round's output below (stores of earlier blocks may still be in flight here)
+  // (Fencing only in rounds whose match sources were not yet known to have landed was measured: 11.3 ms per GiB against
+  // 11.0 with the fence every round; one 128 KiB string 5.05 against 4.81 ms.)
   for (;;) {
     if (!have || rel >= 58 * 32) {
       if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
@@ -379,10 +390,10 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       const uint32_t cw0 = (uint32_t)(absbit >> 5);  // first dword (relative to R.base) held in s_in
       __syncthreads();
       const uint64_t first = ((uint64_t)cw0 + lane) * 4;
-      const uint64_t end = (uint64_t)R.skip + R.nbytes;
+      const uint64_t end = (uint64_t)r_skip + r_nbytes;
       uint32_t x = 0;
       if (first < end) {
-        x = R.base[cw0 + lane];
+        x = r_base[cw0 + lane];
         if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
       }
       s_in[lane] = x;
@@ -426,62 +437,73 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     // (slow / invalid / end of block) advances by 64 bits.
     const bool hard = slow | bad | is_eob;
     const uint32_t P = hard ? 64u : (tok_bits | (out_len << 8));
-    // S: bit j set = a token's output starts j bytes into the round's output (feeds the one-pass copy below)
-    uint32_t acc = 0, k = 0, my_acc = 0xFFFFFFFFu;
-    unsigned long long S = 0;
-    do {
-      my_acc = lane == k ? acc : my_acc;
-      S |= 1ull << ((acc >> 8) & 63);
-      acc += __builtin_amdgcn_readlane(P, k);
-      k = acc & 0xff;
-    } while (k < 64);
+    // The walk is six instructions a token, written out: the lane index lives in M0 (gfx9 wants v_writelane's lane
+    // select there when the value written is a scalar register), v_writelane leaves acc in the token's lane.  (The
+    // compiler's version of the same loop was eleven; with eight waves a SIMD this function is bound by the number of
+    // instructions of every kind that a round issues, not by the vector ones alone.)
+    uint32_t acc = 0, my_acc = 0xFFFFFFFFu, walk_t;
+    asm volatile(
+        "s_mov_b32 m0, 0\n"
+        "1:\n\t"
+        "v_writelane_b32 %[my], %[acc], m0\n\t"
+        "v_readlane_b32 %[t], %[p], m0\n\t"
+        "s_add_u32 %[acc], %[acc], %[t]\n\t"
+        "s_and_b32 m0, %[acc], 0xff\n\t"
+        "s_cmp_lt_u32 m0, 64\n\t"
+        "s_cbranch_scc1 1b"
+        : [my] "+v"(my_acc), [acc] "+s"(acc), [t] "=&s"(walk_t)
+        : [p] "v"(P)
+        : "m0", "scc");
+    const uint32_t k = acc & 0xff;  // where the walk left the window (>= 64)
     const bool is_tok = my_acc != 0xFFFFFFFFu;
     const uint32_t my_off = my_acc >> 8;
-    // ---- stop events, in the reference's order of checks for one token
     const uint32_t my_pos = op + my_off;
+    // a match that reads this round's own output (that includes every self-overlapping one), the dictionary, or
+    // nothing at all (-11)
+    const bool odd = is_len & ((my_pos + mlen > op + dist) | (dist > my_pos));
+    // ---- the plain round: every token passed, the output fits, at most 64 bytes of it, every match source older than
+    // the round.  Written in ONE pass, one lane per output byte: a token's lane leaves what its bytes are made of (the
+    // literal, or the distance) at the token's output offset in LDS; the slots that were written are the offsets where
+    // tokens start; a byte's lane takes the nearest one at or below its own; match bytes are loaded from `dist` back,
+    // all matches of the round by the same load instruction (one memory latency per round, no per-match loop).
+    // (LDS operations of one wave execute in order: no barrier between the writes and the reads.)
+    // (Storing a round later, so that the loads overlap the next decode, was measured: 12.0 ms per GiB against 11.2.)
+    {
+      const uint32_t n_tot = acc >> 8;
+      const bool plain = (n_tot <= 64) & (op + n_tot <= cap) & (rel + k <= lim);  // (uniform)
+      if (plain && ballot64(is_tok & (hard | odd)) == 0) {
+        s_tk[lane] = 0;
+        if (is_tok) s_tk[my_off] = is_len ? (0x80000000u | dist) : (0x40000000u | sym);
+        // (what a lane reads below was written by other lanes: without this the compiler forwards the lane's own 0)
+        asm volatile("" ::: "memory");
+        const unsigned long long below = ballot64(s_tk[lane] != 0) & le_mask;  // (never 0: a token starts at offset 0)
+        const uint32_t info = s_tk[63 - __builtin_clzll(below)];
+        uint32_t v = info;
+        // every store of earlier rounds must have landed before a match source among them is read
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((lane < n_tot) & ((info >> 31) != 0)) v = out[op + lane - (info & 0xFFFFu)];
+        if (lane < n_tot) out[op + lane] = (uint8_t)v;
+        op += n_tot;
+        rel += k;
+        continue;
+      }
+    }
+    // ---- any other round.  Stop events, in the reference's order of checks for one token
     const bool err11 = is_len & (dist > my_pos + ext);  // LD:2406-2410
     const bool full = my_pos + out_len > cap;
     const bool exh = bit + tok_bits > lim;              // LD:2428
     const unsigned long long stops = ballot64(is_tok & (hard | err11 | full | exh));
     const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
     const bool commit = is_tok & (lane < first);
-    // ---- this round's output.  The usual case -- at most 64 bytes, every match source older than this round's
-    // output and inside the output -- is written in ONE pass, one lane per output byte: the byte's token is found from
-    // S, literals come from that token's lane, match bytes are loaded from `dist` back, all matches of the round by
-    // the same load instruction (one memory latency per round instead of one per match, and no per-match loop).
-    // (Storing a round later, so that the loads overlap the next decode, was measured: 12.0 ms per GiB against 11.2.)
-    const uint32_t n_out = first == 64 ? acc >> 8 : __builtin_amdgcn_readlane(my_off, first);
     const bool cm = commit & is_len;
-    // Every store of earlier rounds must have landed before a match source among them is read.  `safe` is the output
-    // position below which every byte is known to have landed (everything stored before the last wait for a load or
-    // fence): kLazyFence pays for the fence only in a round with a match source at or beyond it.
-    if (!kLazyFence || ballot64(cm & (my_pos + mlen > safe + dist))) {
+    {
+      // literals at once, matches in order, each one seeing everything stored before it
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      safe = op;
-    }
-    // a match that reads this round's own output (that includes every self-overlapping one) or the dictionary
-    const bool odd = cm & ((my_pos + mlen > op + dist) | (dist > my_pos));
-    if (n_out <= 64 && ballot64(odd) == 0) {
-      // a token's lane leaves what its bytes are made of (the literal, or the distance) at the token's output offset;
-      // a byte's lane finds its token's offset as the highest bit of S at or below its own (LDS operations of one
-      // wave execute in order: no barrier between the write and the read)
-      if (is_tok & (my_off < 64)) s_tk[my_off] = is_len ? (0x80000000u | dist) : sym;
-      const unsigned long long below = S & le_mask;
-      const uint32_t info = s_tk[below ? 63 - __builtin_clzll(below) : 0];
-      uint32_t v = info;
-      const bool ld = (lane < n_out) & ((info >> 31) != 0);
-      if (ld) v = out[op + lane - (info & 0xFFFFu)];
-      if (kLazyFence && ballot64(ld)) safe = op;  // the store below waits for that load, and so for all earlier stores
-      if (lane < n_out) out[op + lane] = (uint8_t)v;
-    } else {
-      if (kLazyFence) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
       if (commit & is_lit) out[my_pos] = (uint8_t)sym;
       unsigned long long mm = ballot64(cm);
-      while (mm) {  // in order, each one seeing everything stored before it
+      while (mm) {
         const uint32_t j = (uint32_t)__builtin_ctzll(mm);
         mm &= mm - 1;
         const uint32_t len = __builtin_amdgcn_readlane(mlen, j);
@@ -497,11 +519,6 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
             out[dst + i] = a < d ? O.dict[O.dlen - (d - a)] : out[a - d];
           }
         }
-      }
-      if (kLazyFence) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        safe = op + n_out;
       }
     }
     if (first == 64) {  // the whole window was consumed
@@ -520,11 +537,11 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     if (f & 1) {  // unresolved by the tables: wave-uniform decode of this one token
       br_seek_bits(R, bp, lane);
       bool eob = false;
-      const int st = decode_one(LT, DT, 0, 0, R, O, ext, lane, &eob);
+      const int st = (int)uni((uint32_t)decode_one(LT, DT, 0, 0, R, O, ext, lane, &eob));
       if (st != 0) return st;
-      if (eob) return 0;
-      bp = R.consumed;
-      op = (uint32_t)O.opos;
+      if (uni(eob ? 1u : 0u)) return 0;
+      bp = uni64(R.consumed);
+      op = uni((uint32_t)O.opos);
       have = false;
       continue;
     }
@@ -623,12 +640,20 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
     ext = O.dlen;
     O.dict_loaded = true;
   }
-  const uint64_t nbits = (uint64_t)R.nbytes * 8;
-  const uint64_t skip_bits = (uint64_t)R.skip * 8;
-  const uint32_t cap = (uint32_t)O.cap;
-  uint8_t *const out = O.out;
-  uint32_t op = (uint32_t)O.opos;  // output position (uniform)
-  uint64_t bp = R.consumed;        // bits consumed so far (uniform); current only while !have
+  // (The called copy gets its state through references: the compiler cannot tell that what it loads from them is
+  // wave-uniform and would keep positions, pointers and the loop's conditions in vector registers.  v_readfirstlane
+  // says so; in the inlined copy, where they are scalar already, it folds away.)
+  const uint32_t r_nbytes = uni(R.nbytes), r_skip = uni(R.skip);
+  const uint32_t *const r_base = (const uint32_t *)uni64((uint64_t)(uintptr_t)R.base);
+  const uint64_t nbits = (uint64_t)r_nbytes * 8;
+  const uint64_t skip_bits = (uint64_t)r_skip * 8;
+  const uint32_t cap = uni((uint32_t)O.cap);
+  // (a global, not a generic, pointer: loads and stores take the scalar base and a 32-bit lane offset as they are,
+  // without a 64-bit vector add per access, and do not count as LDS operations in the wait counters)
+  typedef __attribute__((address_space(1))) uint8_t *gbytes_t;
+  const gbytes_t out = (gbytes_t)uni64((uint64_t)(uintptr_t)O.out);
+  uint32_t op = uni((uint32_t)O.opos);  // output position (uniform)
+  uint64_t bp = uni64(R.consumed);      // bits consumed so far (uniform); current only while !have
   int64_t bp0 = 0;                 // bits consumed = bp0 + rel while the window is valid
   uint32_t rel = 0;                // bit offset of the current position in the window
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
@@ -656,12 +681,12 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
       const uint64_t absbit = skip_bits + bp;
       const uint32_t cw0 = (uint32_t)(absbit >> 5);  // first dword (relative to R.base) held in Sh.in
       lds_barrier();
-      const uint64_t end = (uint64_t)R.skip + R.nbytes;
+      const uint64_t end = (uint64_t)r_skip + r_nbytes;
       for (uint32_t i = tid; i < kWideWin + 4; i += NT) {
         const uint64_t first = ((uint64_t)cw0 + i) * 4;
         uint32_t x = 0;
         if (first < end) {
-          x = R.base[cw0 + i];
+          x = r_base[cw0 + i];
           if (first + 4 > end) x &= (1u << (8 * (uint32_t)(end - first))) - 1u;  // zeros past the end
         }
         Sh.in[i] = x;
