@@ -26,7 +26,7 @@ template <int LUT_BITS, int NSYM>
 struct DecTabT {
   static constexpr int kBits = LUT_BITS;
   static constexpr int kSize = 1 << LUT_BITS;
-  uint16_t lut[kSize];     // entry for codes of <= kBits bits (see lut_entry); 0 = slow path
+  uint16_t lut[kSize];     // entry for codes of <= kBits bits (see lut_entry)
   uint16_t symbols[NSYM];  // puff order: by (length, symbol)
   uint32_t counts[16];
   uint32_t offs[16];
@@ -38,15 +38,20 @@ using DistTab = DecTabT<9, 32>;
 
 // Lookup entries carry what the lane-parallel decoder needs, ready to use (computing base and
 // extra-bit count of LD:188-240 from the symbol cost a fifth of its vector instructions):
-//   kLutPlain   (sym << 4) | bits                                   code-length alphabet
-//   kLutLitLen  literal / end of block / 286-287:  (sym << 4) | bits, sym 286.. stored as 511
+//   kLutPlain   (sym << 4) | bits; 0 = not in the table                                  code-length alphabet
+//   kLutLitLen  literal:        byte << 4 | bits
 //               length symbol:  1 << 15 | (base - 3) << 7 | extra_bits << 4 | bits
-//   kLutDist    bad << 10 | mant << 8 | extra_bits << 4 | bits:  dist = 1 + (mant << eb) + extra;
-//               bad = symbols 30, 31
+//               end of block:   kLutEob | bits;   286, 287:  kLutBad | bits
+//   kLutDist    mant << 8 | extra_bits << 4 | bits:  dist = 1 + (mant << eb) + extra;   30, 31:  kLutBad | bits
+//   both packed kinds: kLutMiss = the code is longer than the table's index (or no code at all): the canonical walk.
+// Bits 14:13 of an entry that is not a length are its class -- 0 a token the walk passes, else one it cannot -- so that
+// "can the walk pass" is one AND and one compare on (is length ? distance entry : literal entry).
 enum { kLutPlain = 0, kLutLitLen = 1, kLutDist = 2 };
+constexpr uint32_t kLutEob = 0x2000u, kLutBad = 0x4000u, kLutMiss = 0x6000u, kLutClass = 0x6000u;
 __device__ inline uint32_t lut_entry(int mode, uint32_t sym, uint32_t bits) {
   if (mode == kLutLitLen) {
-    if (sym > 285) return (511u << 4) | bits;
+    if (sym > 285) return kLutBad | bits;
+    if (sym == 256) return kLutEob | bits;
     if (sym > 256) {
       const uint32_t ls = sym - 257;
       const uint32_t eb = (ls < 8 || ls == 28) ? 0u : (ls >> 2) - 1;
@@ -54,11 +59,10 @@ __device__ inline uint32_t lut_entry(int mode, uint32_t sym, uint32_t bits) {
       return (1u << 15) | (b3 << 7) | (eb << 4) | bits;
     }
   } else if (mode == kLutDist) {
-    const uint32_t bad = sym > 29 ? 1u : 0u;
-    const uint32_t dsc = bad ? 29u : sym;
-    const uint32_t eb = dsc < 4 ? 0u : (dsc >> 1) - 1;
-    const uint32_t mant = dsc < 4 ? dsc : 2u + (dsc & 1);
-    return (bad << 10) | (mant << 8) | (eb << 4) | bits;
+    if (sym > 29) return kLutBad | bits;
+    const uint32_t eb = sym < 4 ? 0u : (sym >> 1) - 1;
+    const uint32_t mant = sym < 4 ? sym : 2u + (sym & 1);
+    return (mant << 8) | (eb << 4) | bits;
   }
   return (sym << 4) | bits;
 }
@@ -172,7 +176,7 @@ __device__ int build_table(DecTab &T, const uint8_t *lens, int nsym, int max_bit
     T.offs[tid] = 0;
     T.first[tid] = 0;
   }
-  for (int i = tid; i < DecTab::kSize; i += W * kWave) T.lut[i] = 0;
+  for (int i = tid; i < DecTab::kSize; i += W * kWave) T.lut[i] = mode == kLutPlain ? 0 : (uint16_t)kLutMiss;
   __syncthreads();
   for (int base = 0; base < nsym; base += kWave) {
     const int i = base + (int)lane;
@@ -339,6 +343,46 @@ __device__ inline void br_seek_bits(BitReader &R, uint64_t bit_pos, uint32_t lan
   R.consumed = bit_pos;
 }
 
+// What the token that would start at one bit offset decodes to, speculatively (DecodeUntilEndOfBlock's table look-ups,
+// LD:2379-2440, for one lane): w0..w2 are the three dwords of input at the offset's dword, sh its bit in the first.
+// Values of the other kind of token are computed regardless and are garbage (every index stays inside its table).
+struct SpecTok {
+  uint32_t e, e2;      // the literal/length entry and the distance entry
+  uint32_t he;         // the entry that says whether the walk can pass: is_len ? e2 : e
+  bool is_len;         // a match
+  bool hard;           // the walk cannot pass: end of block, a code the tables do not hold, an invalid symbol
+  uint32_t mlen, dist; // the match (is_len && !hard)
+  uint32_t tok_bits;   // bits of the token (of the literal/length code alone for one that is not a match)
+  uint32_t out_len;    // bytes it produces (0 when hard)
+  // the classes (used off the fast path only)
+  __device__ uint32_t cls() const { return he & kLutClass; }
+  __device__ bool is_lit() const { return !is_len & ((e & kLutClass) == 0); }
+  __device__ bool is_eob() const { return !is_len & ((e & kLutClass) == kLutEob); }
+  __device__ bool slow() const { return cls() == kLutMiss; }
+  __device__ bool bad() const { return cls() == kLutBad; }
+  __device__ uint32_t lit() const { return (e >> 4) & 255u; }
+};
+__device__ inline SpecTok spec_decode(const LitTab &LT, const DistTab &DT, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh) {
+  SpecTok T;
+  const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+  T.e = LT.lut[lo & (LitTab::kSize - 1)];
+  const uint32_t l1 = T.e & 15;
+  T.is_len = (T.e >> 15) != 0;
+  const uint32_t leb = (T.e >> 4) & 7;  // (a table hit is at most 10 bits, 5 extra: all inside `lo`)
+  T.mlen = 3 + ((T.e >> 7) & 255) + ((lo >> l1) & ((1u << leb) - 1u));
+  const uint32_t t = l1 + leb;
+  const uint32_t din = __builtin_amdgcn_alignbit(hi, lo, t);  // 32 bits from bit t on: 9 + 13 are needed at most
+  T.e2 = DT.lut[din & (DistTab::kSize - 1)];
+  const uint32_t l2 = T.e2 & 15, deb = (T.e2 >> 4) & 15;
+  T.dist = 1 + (((T.e2 >> 8) & 3) << deb) + ((din >> l2) & ((1u << deb) - 1u));
+  T.he = T.is_len ? T.e2 : T.e;
+  T.hard = (T.he & kLutClass) != 0;
+  T.tok_bits = T.is_len ? t + l2 + deb : l1;
+  T.out_len = T.hard ? 0u : (T.is_len ? T.mlen : 1u);
+  return T;
+}
+
 // DecodeUntilEndOfBlock (LD:2353-2445), lane-parallel.
 // The scalar unit, not the vector lanes, bounded the wave-uniform decoder (every branch and
 // every uniform bit operation is a scalar instruction, one per cycle per CU).  Here lane k
@@ -409,33 +453,13 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     // ---- every lane decodes the token starting `lane` bits ahead
     const uint32_t bit = rel + lane;
     const uint32_t di = bit >> 5, sh = bit & 31;
-    const uint32_t w0 = s_in[di], w1 = s_in[di + 1], w2 = s_in[di + 2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    const uint64_t win = ((uint64_t)hi << 32) | lo;
-    const uint32_t e = LT.lut[lo & (LitTab::kSize - 1)];
-    const uint32_t l1 = e & 15;
-    const bool is_len = (e >> 15) != 0;
-    const uint32_t sym = (e >> 4) & 511;  // meaningful when !is_len
-    const bool is_lit = !is_len & (sym < 256), is_eob = !is_len & (sym == 256);
-    bool slow = e == 0;
-    bool bad = !is_len & (sym == 511);
-    const uint32_t leb = is_len ? (e >> 4) & 7 : 0u;
-    const uint32_t mlen = 3 + ((e >> 7) & 255) + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
-    const uint32_t t = l1 + leb;
-    const uint32_t din = (uint32_t)(win >> t);
-    const uint32_t e2 = DT.lut[din & (DistTab::kSize - 1)];
-    const uint32_t l2 = e2 & 15, deb = (e2 >> 4) & 15;
-    slow = slow | (is_len & (e2 == 0));
-    bad = bad | (is_len & ((e2 >> 10) != 0));
-    const uint32_t dist = 1 + (((e2 >> 8) & 3) << deb) + ((din >> l2) & ((1u << deb) - 1u));
-    const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
-    const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
+    const SpecTok T = spec_decode(LT, DT, s_in[di], s_in[di + 1], s_in[di + 2], sh);
+    const bool is_len = T.is_len, hard = T.hard;
+    const uint32_t mlen = T.mlen, dist = T.dist, tok_bits = T.tok_bits, out_len = T.out_len;
 
     // ---- walk the chain of real tokens from lane 0.  acc = bits walked | output bytes << 8;
     // each token's lane receives acc as it was at its start.  A token the walk cannot pass
     // (slow / invalid / end of block) advances by 64 bits.
-    const bool hard = slow | bad | is_eob;
     const uint32_t P = hard ? 64u : (tok_bits | (out_len << 8));
     // The walk is six instructions a token, written out: the lane index lives in M0 (gfx9 wants v_writelane's lane
     // select there when the value written is a scalar register), v_writelane leaves acc in the token's lane.  (The
@@ -473,12 +497,12 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       const bool plain = (n_tot <= 64) & (op + n_tot <= cap) & (rel + k <= lim);  // (uniform)
       if (plain && ballot64(is_tok & (hard | odd)) == 0) {
         s_tk[lane] = 0;
-        if (is_tok) s_tk[my_off] = is_len ? (0x80000000u | dist) : (0x40000000u | sym);
+        if (is_tok) s_tk[my_off] = is_len ? (0x80000000u | dist) : (0x40000000u | T.e);  // (a literal: its entry, byte << 4)
         // (what a lane reads below was written by other lanes: without this the compiler forwards the lane's own 0)
         asm volatile("" ::: "memory");
         const unsigned long long below = ballot64(s_tk[lane] != 0) & le_mask;  // (never 0: a token starts at offset 0)
         const uint32_t info = s_tk[63 - __builtin_clzll(below)];
-        uint32_t v = info;
+        uint32_t v = info >> 4;
         // every store of earlier rounds must have landed before a match source among them is read
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -501,7 +525,7 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       // literals at once, matches in order, each one seeing everything stored before it
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (commit & is_lit) out[my_pos] = (uint8_t)sym;
+      if (commit & T.is_lit()) out[my_pos] = (uint8_t)T.lit();
       unsigned long long mm = ballot64(cm);
       while (mm) {
         const uint32_t j = (uint32_t)__builtin_ctzll(mm);
@@ -527,8 +551,8 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       continue;
     }
     // ---- the stopping token
-    const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
-                        (exh ? 16u : 0u) | (is_eob ? 32u : 0u);
+    const uint32_t fl = (T.slow() ? 1u : 0u) | (T.bad() ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) |
+                        (exh ? 16u : 0u) | (T.is_eob() ? 32u : 0u);
     const uint32_t f = __builtin_amdgcn_readlane(fl, first);
     op += __builtin_amdgcn_readlane(my_off, first);
     O.opos = op;
@@ -703,29 +727,9 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
     // ---- every thread decodes the token starting `tid` bits ahead (decode_block's code)
     const uint32_t bit = rel + tid;
     const uint32_t di = bit >> 5, sh = bit & 31;
-    const uint32_t w0 = Sh.in[di], w1 = Sh.in[di + 1], w2 = Sh.in[di + 2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    const uint64_t win = ((uint64_t)hi << 32) | lo;
-    const uint32_t e = LT.lut[lo & (LitTab::kSize - 1)];
-    const uint32_t l1 = e & 15;
-    const bool is_len = (e >> 15) != 0;
-    const uint32_t sym = (e >> 4) & 511;  // meaningful when !is_len
-    const bool is_lit = !is_len & (sym < 256), is_eob = !is_len & (sym == 256);
-    bool slow = e == 0;
-    bool bad = !is_len & (sym == 511);
-    const uint32_t leb = is_len ? (e >> 4) & 7 : 0u;
-    const uint32_t mlen = 3 + ((e >> 7) & 255) + ((uint32_t)(win >> l1) & ((1u << leb) - 1u));
-    const uint32_t t = l1 + leb;
-    const uint32_t din = (uint32_t)(win >> t);
-    const uint32_t e2 = DT.lut[din & (DistTab::kSize - 1)];
-    const uint32_t l2 = e2 & 15, deb = (e2 >> 4) & 15;
-    slow = slow | (is_len & (e2 == 0));
-    bad = bad | (is_len & ((e2 >> 10) != 0));
-    const uint32_t dist = 1 + (((e2 >> 8) & 3) << deb) + ((din >> l2) & ((1u << deb) - 1u));
-    const uint32_t tok_bits = is_len ? t + l2 + deb : l1;
-    const uint32_t out_len = is_lit ? 1u : (is_len ? mlen : 0u);
-    const bool hard = slow | bad | is_eob;
+    const SpecTok T = spec_decode(LT, DT, Sh.in[di], Sh.in[di + 1], Sh.in[di + 2], sh);
+    const bool is_len = T.is_len, hard = T.hard;
+    const uint32_t mlen = T.mlen, dist = T.dist, tok_bits = T.tok_bits, out_len = T.out_len;
     // ---- pointer jumping inside the wavefront's row of 64 offsets: X = where the path from this offset stands
     // (row coordinates; 64 and more: it has left the row; kHardJ: it ended at a token that cannot be passed) | the
     // bytes its tokens produce; V = the offsets it visited
@@ -790,8 +794,8 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
     // a match that reads this round's own output (that includes every self-overlapping one) or the dictionary
     const bool odd = is_tok & is_len & ((my_pos + mlen > op + dist) | (dist > my_pos));
     const unsigned long long odds = ballot64(odd);
-    const uint32_t fl = (slow ? 1u : 0u) | (bad ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) | (exh ? 16u : 0u) |
-                        (is_eob ? 32u : 0u);
+    const uint32_t fl = (T.slow() ? 1u : 0u) | (T.bad() ? 2u : 0u) | (err11 ? 4u : 0u) | (full ? 8u : 0u) | (exh ? 16u : 0u) |
+                        (T.is_eob() ? 32u : 0u);
     {
       const uint32_t sl = stops ? (uint32_t)__builtin_ctzll(stops) : 0u;
       const uint32_t s_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)sl);
@@ -803,7 +807,7 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
       }
     }
     if (is_tok & (my_off < NT)) {
-      Sh.tk[my_off] = is_len ? (0x80000000u | (dist - 1)) : sym;
+      Sh.tk[my_off] = is_len ? (0x80000000u | (dist - 1)) : T.lit();
       atomicOr(&S[my_off >> 5], 1u << (my_off & 31));
     }
     if (tid < W * 2 + 2) S_next[tid] = 0;
@@ -883,7 +887,7 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
       // more bytes than threads: in order -- literals by their threads, then every match by the whole workgroup, each
       // one seeing what was stored before it
       const bool commit = is_tok & (tid < first);
-      if (commit & is_lit) out[my_pos] = (uint8_t)sym;
+      if (commit & T.is_lit()) out[my_pos] = (uint8_t)T.lit();
       const unsigned long long cmm = ballot64(commit & is_len);
       Sh.tk[tid] = (mlen << 16) | (dist - 1);
       Sh.acc[tid] = my_off;
