@@ -421,14 +421,14 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   uint32_t op = uni((uint32_t)O.opos);  // output position (uniform)
   uint64_t bp = uni64(R.consumed);      // bits consumed so far (uniform); current only while !have
   int64_t bp0 = 0;                 // bits consumed = bp0 + rel while the window is valid
-  uint32_t rel = 0;                // bit offset of the current position in the window
+  uint32_t rel = 0xFFFFFFFFu;      // bit offset of the current position in the window (all ones while there is none)
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
   bool have = false;
   const unsigned long long le_mask = (2ull << lane) - 1ull;  // lanes 0..lane
   // (Fencing only in rounds whose match sources were not yet known to have landed was measured: 11.3 ms per GiB against
   // 11.0 with the fence every round; one 128 KiB string 5.05 against 4.81 ms.)
   for (;;) {
-    if (!have || rel >= 58 * 32) {
+    if (rel >= 58 * 32) {  // (also: no window yet)
       if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
       const uint64_t absbit = skip_bits + bp;
       const uint32_t cw0 = (uint32_t)(absbit >> 5);  // first dword (relative to R.base) held in s_in
@@ -494,8 +494,8 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     // (Storing a round later, so that the loads overlap the next decode, was measured: 12.0 ms per GiB against 11.2.)
     {
       const uint32_t n_tot = acc >> 8;
-      const bool plain = (n_tot <= 64) & (op + n_tot <= cap) & (rel + k <= lim);  // (uniform)
-      if (plain && ballot64(is_tok & (hard | odd)) == 0) {
+      // (uniform tests, as branches: as one boolean they cost the scalar unit a select and an OR each)
+      if (n_tot <= 64 && op + n_tot <= cap && rel + k <= lim && ballot64(is_tok & (hard | odd)) == 0) {
         s_tk[lane] = 0;
         if (is_tok) s_tk[my_off] = is_len ? (0x80000000u | dist) : (0x40000000u | T.e);  // (a literal: its entry, byte << 4)
         // (what a lane reads below was written by other lanes: without this the compiler forwards the lane's own 0)
@@ -567,6 +567,7 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       bp = uni64(R.consumed);
       op = uni((uint32_t)O.opos);
       have = false;
+      rel = 0xFFFFFFFFu;
       continue;
     }
     R.consumed = bp;
