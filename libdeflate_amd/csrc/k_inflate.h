@@ -957,13 +957,12 @@ __device__ int decode_block_wide(const LitTab &LT, const DistTab &DT, BitReader 
   }
 }
 
-// The block body as a function of its own.  Inlined at its two call sites it shares k_inflate's scalar registers
-// with the header code around it, and the round loop reloads spilled ones through v_readlane / v_writelane: with the
-// chip full of waves (instruction issue is the bound) the call is faster, 11.0 -> 10.6 ms per GiB at 8192 streams
-// (70 SGPRs, 56 VGPRs of its own, one call per deflate block); a wave that runs alone is bound by latency and is
-// faster with the inlined body (one 16 MiB stream: 520 against 570 ms).  Hence two kernels, chosen by batch size
-// (the call is kept a call by a statement attribute; a noinline wrapper around the inlinable body sent this
-// compiler's backend into "Illegal instruction detected" on the LDS pointers' address-space casts).
+// The block body can be a function of its own (BODY_CALL: kept a call by a statement attribute; a noinline wrapper
+// around the inlinable body sent this compiler's backend into "Illegal instruction detected" on the LDS pointers'
+// address-space casts).  In round 2 the call was the faster form with the chip full of waves (10.6 against 11.0 ms per
+// GiB: inlined, the round loop shared k_inflate's scalar registers with the header code and reloaded spilled ones).
+// With the round as it is now the inlined body wins at every batch size (7.0 against 7.3 ms at 8192 streams, 4.6
+// against 5.0 at 2048); k_inflate, the form with the call, stays selectable (LDH_INFLATE_CALL_MIN) for comparison.
 // W: wavefronts per stream (1: k_inflate / k_inflate_alone; more: k_inflate_wide, whose block body is decode_block_wide;
 // everything around the body is the same wave-uniform code, run by all W wavefronts alike, stores made once).
 template <int W, bool BODY_CALL>

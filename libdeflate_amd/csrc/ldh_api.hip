@@ -581,14 +581,16 @@ int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off
   A.bytes_left = d_bytes_left;
   A.status = d_status;
   A.expect_adler = expect;
-  // One wavefront per stream when the batch has streams enough to keep the chip busy that way (k_inflate: the block
-  // body as a call from 4096 streams on, inlined below that); fewer streams get a workgroup of four or eight
+  // One wavefront per stream when the batch has streams enough to keep the chip busy that way (k_inflate_alone: the block
+  // body inlined; k_inflate, with the body as a call, is kept for comparison); fewer streams get a workgroup of four or eight
   // wavefronts each, a round speculating on 256 / 512 bit offsets (decode_block_wide).  Measured on 128 KiB streams
-  // (tools/inflate_rate.py, ms for 1 / 256 / 1024 / 2048 / 4096 streams): one wavefront 4.1 / 4.4 / 4.8 / 5.8 / 7.3,
-  // four 2.3 / 2.5 / 3.3 / 6.6 / 12.8, eight 1.6 / 1.8 / 4.4 / 8.7 / 17.  LDH_INFLATE_WAVES=1/2/4/8 forces a form.
-  static const int body_call_min = getenv("LDH_INFLATE_CALL_MIN") ? atoi(getenv("LDH_INFLATE_CALL_MIN")) : 4096;
-  static const int wide4_max = getenv("LDH_INFLATE_WIDE4_MAX") ? atoi(getenv("LDH_INFLATE_WIDE4_MAX")) : 1792;
-  static const int wide8_max = getenv("LDH_INFLATE_WIDE8_MAX") ? atoi(getenv("LDH_INFLATE_WIDE8_MAX")) : 640;
+  // (tools/inflate_rate.py, ms for 1 / 256 / 512 / 1024 / 1280 / 2048 streams): one wavefront 3.1 / 3.3 / 3.4 / 3.7 / 4.0 /
+  // 4.6, four 2.3 / 2.5 / 2.8 / 3.2 / 5.3 / 6.5, eight 1.6 / 1.8 / 2.3 / 4.4 / 5.6 / 8.8: the wide forms run four
+  // wavefronts a SIMD, so 512 x 8 and 1024 x 4 wavefronts are what the chip holds at once, and one stream more starts a
+  // second shift.  LDH_INFLATE_WAVES=1/2/4/8 forces a form.
+  static const int body_call_min = getenv("LDH_INFLATE_CALL_MIN") ? atoi(getenv("LDH_INFLATE_CALL_MIN")) : (1 << 30);
+  static const int wide4_max = getenv("LDH_INFLATE_WIDE4_MAX") ? atoi(getenv("LDH_INFLATE_WIDE4_MAX")) : 1025;
+  static const int wide8_max = getenv("LDH_INFLATE_WIDE8_MAX") ? atoi(getenv("LDH_INFLATE_WIDE8_MAX")) : 513;
   const char *force = getenv("LDH_INFLATE_WAVES");
   const int waves = force ? atoi(force) : (count < (size_t)wide8_max ? 8 : (count < (size_t)wide4_max ? 4 : 1));
   if (waves == 8)
