@@ -31,17 +31,35 @@ def _lua_type(v):
     return "userdata"
 
 
+_UNBUILT = object()  # Dictionary.hash_tables before anybody has looked at it
+
+
 class Dictionary(object):
     """Preset dictionary object (LibDeflate.lua:531-595): same visible fields
-    (adler32, strlen, string_table); the hash_tables of the reference live on the device
-    as the trigram chains that k_sort_links builds over dict ++ input."""
+    (adler32, strlen, string_table, hash_tables).  The compressor does not read hash_tables -- on the
+    device the dictionary's chains are the trigram links that k_sort_links / k_seg_links build over
+    dict ++ input -- so the table the reference builds eagerly (LibDeflate.lua:531-577: key = the trigram's
+    24-bit value, value = the positions i - strlen, in ascending order) is made here when somebody looks."""
 
     def __init__(self, data, adler32):
         self.adler32 = adler32
         self.strlen = len(data)
         self.string_table = bytes(data)
-        self.hash_tables = {}
+        self._hash_tables = _UNBUILT
         self._handle = None
+
+    @property
+    def hash_tables(self):
+        if self._hash_tables is _UNBUILT:
+            t, b, n = {}, self.string_table, len(self.string_table)
+            for i in range(n - 2):  # LibDeflate.lua:560-577 (1-based i + 1; the value is (i + 1) - strlen)
+                t.setdefault((b[i] << 16) | (b[i + 1] << 8) | b[i + 2], []).append(i + 1 - n)
+            self._hash_tables = t
+        return self._hash_tables
+
+    @hash_tables.setter
+    def hash_tables(self, value):
+        self._hash_tables = value
 
     def handle(self):
         if self._handle is None:
@@ -66,7 +84,8 @@ def _is_valid_dictionary(d):  # LibDeflate.lua:602-615
         return False, "'dictionary' - table expected got '%s'." % _lua_type(d)
     if (not isinstance(d.adler32, (int, float)) or not isinstance(d.string_table, (bytes, bytearray))
             or not isinstance(d.strlen, int) or d.strlen <= 0 or d.strlen > 32768
-            or d.strlen != len(d.string_table) or not isinstance(d.hash_tables, dict)):
+            or d.strlen != len(d.string_table)
+            or not (d._hash_tables is _UNBUILT or isinstance(d._hash_tables, dict))):
         return False, "'dictionary' - corrupted dictionary."
     return True, ""
 
@@ -322,4 +341,32 @@ class Codec(object):
         return batch.codec_decode_batch(self, [bytes(s)])[0]
 
 
+# -- LibDeflate.lua:1184-1197: str[index] goes to t[index - offset] for index in [start, stop] (1-based, as in Lua)
+def _load_string_to_table(s, t, start, stop, offset):
+    for index in range(start, stop + 1):
+        t[index - offset] = s[index - 1]
+    return t
+
+
+_PRINT_ALPHABET = b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789()"  # LibDeflate.lua:3165-3297
+
+
+class _Internals(object):
+    """LibDeflate.internals (LibDeflate.lua:3426-3433): what the reference exposes to its own tests."""
+    LoadStringToTable = staticmethod(_load_string_to_table)
+    IsValidDictionary = staticmethod(_is_valid_dictionary)
+    IsEqualAdler32 = staticmethod(lambda actual, expected: (actual % 4294967296) == (expected % 4294967296))
+    _byte_to_6bit_char = {i: _PRINT_ALPHABET[i:i + 1] for i in range(64)}
+    _6bit_to_byte = {c: i for i, c in enumerate(_PRINT_ALPHABET)}
+
+    @staticmethod
+    def InternalClearCache():  # LibDeflate.lua:3419-3422
+        _LibDeflate._addon = None
+        _LibDeflate._chat = None
+        LibDeflate._addon = None
+        LibDeflate._chat = None
+
+
 LibDeflate = _LibDeflate()
+LibDeflate.internals = _Internals
+

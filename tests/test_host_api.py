@@ -100,3 +100,56 @@ def test_product_has_no_cpu_fallback():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "ld_oracle" not in txt and "libld_oracle" not in txt, f
+
+
+# ---- T:732-758 CreateAndCheckDictionary's structure check and T:1637-1670 TestInternals:TestLoadString, against the
+# mirror (the device never reads hash_tables: its chains are the links over dict ++ input; the mirror builds the
+# reference's table on demand so that code written against the reference's dictionary object keeps working)
+def test_dictionary_object_has_the_references_structure():
+    import random
+    from libdeflate_amd.LibDeflate import Dictionary, LibDeflate as LD
+    from ldtest import golden, o_adler32
+    rng = random.Random(7)
+    cases = [b"a", b"ab", b"abc", b"abcabc", b"\0" * 40, bytes(rng.randrange(4) for _ in range(500)),
+             golden("dictionary32768.txt")]
+    for s in cases:
+        d = Dictionary(s, o_adler32(s))              # (CreateDictionary itself needs the GPU for Adler-32)
+        assert LD.internals.IsValidDictionary(d)[0]
+        n = len(s)
+        assert d.strlen == n
+        for i in range(1, n + 1):
+            assert d.string_table[i - 1] == s[i - 1]
+        for i in range(1, n - 1):                     # T:741-756: every trigram's chain holds i - strlen
+            h = s[i - 1] * 65536 + s[i] * 256 + s[i + 1]
+            chain = d.hash_tables.get(h)
+            assert chain is not None, "nil hash_chain?"
+            assert (i - n) in chain, "hash index %d not found in dictionary hash_table." % i
+        # LD:560-577 appends in ascending i: chains are ordered, and nothing else is in the table
+        assert all(c == sorted(c) for c in d.hash_tables.values())
+        assert sum(len(c) for c in d.hash_tables.values()) == max(n - 2, 0)
+
+
+def test_internals_load_string_to_table():
+    import random
+    from libdeflate_amd.LibDeflate import LibDeflate as LD
+    load = LD.internals.LoadStringToTable
+    rng = random.Random(11)
+    for _ in range(50):                               # T:1641-1669
+        strlen = rng.randint(0, 1000)
+        s = bytes(rng.randrange(256) for _ in range(strlen))
+        untouched = {i: rng.randint(1, 12345) for i in range(1, strlen + 1)}
+        t = dict(untouched)
+        if strlen >= 1:
+            start, stop = sorted((rng.randint(1, strlen), rng.randint(1, strlen)))
+        else:
+            start, stop = 1, 0
+        offset = rng.randint(0, strlen)
+        assert load(s, t, start, stop, offset) is t
+        for i in range(-1000, 2001):
+            if i < start - offset or i > stop - offset:
+                assert t.get(i) == untouched.get(i), "loadStr corrupts unintended location"
+            else:
+                assert t[i] == s[i + offset - 1], "loadStr gives wrong data!, start=%d, stop=%d, i=%d" % (start, stop, i)
+    assert LD.internals.IsEqualAdler32(4072834167, -222133129)     # LD:444-449
+    assert LD.internals._byte_to_6bit_char[0] == b"a" and LD.internals._6bit_to_byte[ord(")")] == 63
+    assert sorted(LD.internals._6bit_to_byte.values()) == list(range(64))
