@@ -46,7 +46,7 @@ def piece(n):
 t0 = time.time()
 rounds = checked = 0
 while time.time() - t0 < budget:
-    level = int(rng.choice([4, 5, 5, 6, 7, 8, 9, 1, 3]))
+    level = int(rng.choice([4, 5, 5, 6, 7, 8, 9, 1, 1, 2, 3]))
     fmt = int(rng.integers(0, 2))
     dn = int(rng.choice([0, 0, 1, 300, 32768]))
     d = dicts.get(dn)
