@@ -1067,8 +1067,14 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
       total += nidle[i];
     }
     if (REFILL_MIN <= 1 || total >= (uint32_t)REFILL_MIN * NW) {
+      // (one ds_add_rtn by lane 0, written out: the compiler's atomic optimiser turns a single-lane atomicAdd into its
+      // generic wave reduction -- a scalar loop over the exec bits, v_writelane, two mbcnt -- some 25 instructions a round)
       uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&s_next, total);
+      if (lane == 0)
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=v"(base)
+                     : "v"((uint32_t)(uintptr_t)&s_next), "v"(total)
+                     : "memory");
       base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
       for (int i = 0; i < NW; i++) {
@@ -1778,12 +1784,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       uint32_t maxlen_l = be - p;  // (this lane's position)
       maxlen_l = maxlen_l > kMaxMatch ? kMaxMatch : maxlen_l;
       // not final: uncertain, needs more candidates, or a length of "18 or more"
-#if defined(LDH_G2_STOP) && LDH_G2_STOP >= 2  // timing experiments only (results are wrong): every lane counts as final
-      const unsigned long long special = 0;
-#else
       const unsigned long long special =
           ballot64(valid & ((st1 != ST_DONE) | (m1 & (best1 >= kCandLenCap) & (maxlen_l > kCandLenCap))));
-#endif
       const uint32_t tok1 = m1 ? tok_match(best1, bd1) : litv;
       uint32_t cur = 0, nt = 0;
       while (cur < limit) {
@@ -1908,9 +1910,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             }
             dleft -= (uint32_t)__popcll(selm);
             if (nicem || first_bad < (uint32_t)K || dleft == 0 || !more) break;
-#if defined(LDH_G2_STOP) && LDH_G2_STOP >= 1  // timing experiments only (results are wrong): no trip beyond the first
-            break;
-#endif
             cl = (uint32_t)__builtin_amdgcn_readlane((int)q, K - 1);
             e = e_next;
             if (first_trip) {

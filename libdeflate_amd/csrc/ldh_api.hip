@@ -644,9 +644,13 @@ size_t piece_bytes() {
 }
 // A stream takes milliseconds to inflate however few there are, so decompression wants many streams per piece: 128 MiB
 // of results (1024 streams of 128 KiB: k_inflate_wide's range; 256 MiB and one wavefront per stream before round 3)
-size_t inflate_piece_bytes() {
-  static const size_t mult = getenv("LDH_INFLATE_PIECE_MULT") ? (size_t)atoi(getenv("LDH_INFLATE_PIECE_MULT")) : 2;
-  return std::max<size_t>(mult, 1) * piece_bytes();
+// -- for batches up to a few thousand streams.  A large batch is better served by pieces of 256 MiB (2048 streams, one
+// wavefront each: 4.6 ms against two wide launches of 3.2): there are pieces enough to hide the copies anyway.
+size_t inflate_piece_bytes(size_t total_out) {
+  static const size_t forced = getenv("LDH_INFLATE_PIECE_MULT") ? (size_t)atoi(getenv("LDH_INFLATE_PIECE_MULT")) : 0;
+  static const size_t big_from = getenv("LDH_INFLATE_BIG_FROM_MB") ? (size_t)atoi(getenv("LDH_INFLATE_BIG_FROM_MB")) : 768;
+  const size_t mult = forced ? forced : (total_out >= (big_from << 20) ? 4 : 2);
+  return mult * piece_bytes();
 }
 int ensure_pinned(PinBuf &b, size_t bytes) {
   if (bytes <= b.cap) return 0;
@@ -1244,7 +1248,10 @@ static int compress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *in
       bool contiguous;  // streams idx[first] .. idx[last-1] are neighbours in the caller's batch
     };
     std::vector<Piece> pieces;
-    const size_t piece = piece_bytes();
+    // (a large batch in pieces of 128 MiB: 1024 streams of 128 KiB let a workgroup of the link and match kernels take a
+    // whole stream; 8192 x 128 KiB from pinned memory 24.6 -> 26.1 GB/s)
+    static const size_t big_from = getenv("LDH_COMPRESS_BIG_FROM_MB") ? (size_t)atoi(getenv("LDH_COMPRESS_BIG_FROM_MB")) : 768;
+    const size_t piece = piece_bytes() * ((!getenv("LDH_PIECE_KB") && in_off[count] - in_off[0] >= (big_from << 20)) ? 2 : 1);
     for (size_t i = 0; i < g.idx.size();) {
       Piece pc{i, i, 0, true};
       while (pc.last < g.idx.size() && (pc.last == pc.first || pc.bytes < piece)) {
@@ -1377,7 +1384,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     size_t first, last;
   };
   std::vector<Piece> pieces;
-  const size_t piece = inflate_piece_bytes();
+  const size_t piece = inflate_piece_bytes(count * out_stride);
   for (size_t i = 0; i < count;) {
     size_t j = i + 1;
     while (j < count && (j - i + 1) * out_stride <= piece && in_off[j + 1] - in_off[i] <= piece) j++;
