@@ -930,7 +930,9 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   };
   Walk w[NW];
   bool exhausted = false;
-  const uint64_t lane_bit = 1ull << lane;
+  // "is my lane in this wave-uniform mask": the mask itself as the condition (v_cmp-free inverse ballot), not an AND
+  // with the lane's bit and a 64-bit compare (three vector instructions a test, a dozen a round)
+  auto in_mask = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
 
   // x -= 1 in the lanes of a wave-uniform mask: one subtract-with-borrow whose borrow-in is the
   // mask (the compiler's own choice is a select of 0 / 1 and a subtract)
@@ -960,18 +962,19 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     const unsigned long long cm = W.act & W.pm;
     W.pm = 0;
     if (cm) {
-      if (cm & lane_bit) {
+      if (in_mask(cm)) {
         const uint64_t x = lds_load8(lbytes, W.cb + 3) ^ W.tw;
         uint32_t L = 3 + (x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u);
         // the tail of a long match, 8 bytes per trip: a wave-uniform loop over the lanes still equal
         // (per-lane `break`s cost some 25 scalar instructions of mask bookkeeping per trip)
-        unsigned long long going = ballot64((x == 0) & (L < W.maxlen));
+        // (one ballot per compare, combined as masks: a ballot of a combined predicate goes through a 0/1 register)
+        unsigned long long going = ballot64(x == 0) & ballot64(L < W.maxlen);
         while (going) {  // (bytes are staged 280 past the tile's end: reading past maxlen is safe)
           const bool on = __builtin_amdgcn_inverse_ballot_w64(going);
           const uint64_t y = lds_load8(lbytes, W.cb + L) ^ lds_load8(lbytes, W.vb + L);
           const uint32_t adv = y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8u;
           L += on ? adv : 0u;
-          going &= ballot64((y == 0) & (L < W.maxlen));
+          going &= ballot64(y == 0) & ballot64(L < W.maxlen);
         }
         if (L > W.maxlen) L = W.maxlen;
         if ((L << 16) > W.res) {  // L > best (distances are below 65536); LD:1385 strict: nearest of equal lengths wins
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
       }
       // a match of maxlen cannot be beaten (the walk has no side effects, so ending it early
       // leaves the result unchanged)
-      const unsigned long long open = ballot64(((W.res >> 16) < nice) & ((W.res >> 16) < W.maxlen));
+      const unsigned long long open = ballot64((W.res >> 16) < nice) & ballot64((W.res >> 16) < W.maxlen);
       unsigned long long go;
       LDH_HOP(W, cm & open, W.dn, go);
       W.act = (W.act & ~cm) | go;
@@ -996,10 +999,11 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
     // it, per trip.  An idle lane's walk state is dead, so it is overwritten even when the lane
     // gets no position or one that is not searched (LD:1349): that one keeps best = 0 and is
     // stored like any other result at the lane's next refill.)
-    const bool mine = (idle & lane_bit) != 0;
-    if (mine && (W.pend & lane_bit)) mout[W.q] = W.res;
-    const uint32_t my = base + (uint32_t)__popcll(idle & (lane_bit - 1ull));
-    const bool has_pos = mine & (my < q1);
+    const bool mine = in_mask(idle);
+    if (in_mask(idle & W.pend)) mout[W.q] = W.res;
+    const uint32_t my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+    const unsigned long long hp = idle & ballot64(my < q1);  // idle lanes that get a position
+    const bool has_pos = in_mask(hp);
     const uint32_t myc = has_pos ? my : q0;  // (keeps the LDS addresses below inside the staged range)
     const uint32_t p = myc + 1;
     const uint32_t be = p <= be_lo ? be_lo : be_hi;
@@ -1024,14 +1028,13 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
       W.dn = dnn;
     }
     // LD:1349 (the last two positions of a block are not searched); chain empty (0xFFFF) / LD:1365
-    const bool started = has_pos & (p + 2 <= be) & (d0 <= kWindow);
-    const unsigned long long st = ballot64(started);
+    const unsigned long long st = hp & ballot64(p + 2 <= be) & ballot64(d0 <= kWindow);
     W.act |= st;
     // the first candidate of a chain always passes the reject (best = 0: the bytes tested are
     // the trigram's): hand it to the full compare at once instead of freezing the lane on it
     // for a round
     W.pm |= st;
-    W.pend = (W.pend & ~idle) | ballot64(has_pos);
+    W.pend = (W.pend & ~idle) | hp;
     if (HAS_DICT) W.seed = (W.seed & ~idle) | (st & ballot64((W.cb + wbase < D) & !(W.cb + wbase + 2 < D)));
   };
 
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(THREADS) void k_match_lazy(Batch B, uint32_t tiles_
   if (!more) {
 #pragma unroll
     for (int i = 0; i < NW; i++)
-      if (w[i].pend & lane_bit) mout[w[i].q] = w[i].res;
+      if (in_mask(w[i].pend)) mout[w[i].q] = w[i].res;
     break;
   }
   // ---- the next tile of the run (a lane that is done keeps its result until its next refill, as within a tile)
