@@ -428,6 +428,13 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   // (Fencing only in rounds whose match sources were not yet known to have landed was measured: 11.3 ms per GiB against
   // 11.0 with the fence every round; one 128 KiB string 5.05 against 4.81 ms.)
   for (;;) {
+    // (The plain rounds are a loop of their own inside the loop over all rounds: what is carried from one round to the
+    // next -- positions, the window's base and limit -- then keeps its registers; with one loop the paths through the
+    // general case made the compiler shuffle a dozen scalar registers at every back edge.)
+    SpecTok T;
+    uint32_t bit, acc, k, my_off, my_pos;
+    bool is_tok;
+    for (;;) {
     if (rel >= 58 * 32) {  // (also: no window yet)
       if (have) bp = (uint64_t)(bp0 + (int64_t)rel);
       const uint64_t absbit = skip_bits + bp;
@@ -451,9 +458,9 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
       have = true;
     }
     // ---- every lane decodes the token starting `lane` bits ahead
-    const uint32_t bit = rel + lane;
+    bit = rel + lane;
     const uint32_t di = bit >> 5, sh = bit & 31;
-    const SpecTok T = spec_decode(LT, DT, s_in[di], s_in[di + 1], s_in[di + 2], sh);
+    T = spec_decode(LT, DT, s_in[di], s_in[di + 1], s_in[di + 2], sh);
     const bool is_len = T.is_len, hard = T.hard;
     const uint32_t mlen = T.mlen, dist = T.dist, tok_bits = T.tok_bits, out_len = T.out_len;
 
@@ -465,7 +472,8 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     // select there when the value written is a scalar register), v_writelane leaves acc in the token's lane.  (The
     // compiler's version of the same loop was eleven; with eight waves a SIMD this function is bound by the number of
     // instructions of every kind that a round issues, not by the vector ones alone.)
-    uint32_t acc = 0, my_acc = 0xFFFFFFFFu, walk_t;
+    uint32_t my_acc = 0xFFFFFFFFu, walk_t;
+    acc = 0;
     asm volatile(
         "s_mov_b32 m0, 0\n"
         "1:\n\t"
@@ -478,10 +486,10 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
         : [my] "+v"(my_acc), [acc] "+s"(acc), [t] "=&s"(walk_t)
         : [p] "v"(P)
         : "m0", "scc");
-    const uint32_t k = acc & 0xff;  // where the walk left the window (>= 64)
-    const bool is_tok = my_acc != 0xFFFFFFFFu;
-    const uint32_t my_off = my_acc >> 8;
-    const uint32_t my_pos = op + my_off;
+    k = acc & 0xff;  // where the walk left the window (>= 64)
+    is_tok = my_acc != 0xFFFFFFFFu;
+    my_off = my_acc >> 8;
+    my_pos = op + my_off;
     // a match that reads this round's own output (that includes every self-overlapping one), the dictionary, or
     // nothing at all (-11)
     const bool odd = is_len & ((my_pos + mlen > op + dist) | (dist > my_pos));
@@ -513,7 +521,11 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
         continue;
       }
     }
+    break;
+    }
     // ---- any other round.  Stop events, in the reference's order of checks for one token
+    const bool is_len = T.is_len, hard = T.hard;
+    const uint32_t mlen = T.mlen, dist = T.dist, tok_bits = T.tok_bits, out_len = T.out_len;
     const bool err11 = is_len & (dist > my_pos + ext);  // LD:2406-2410
     const bool full = my_pos + out_len > cap;
     const bool exh = bit + tok_bits > lim;              // LD:2428
