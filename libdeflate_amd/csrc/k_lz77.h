@@ -821,6 +821,10 @@ constexpr uint32_t kMatchLdsBytes = kLdsByteCap + 2 * kLdsPrevCap;
 #define LDH_REFILL_MIN_DEEP 12
 #endif
 constexpr int kRefillMinDeep = LDH_REFILL_MIN_DEEP;  // REFILL_MIN of k_match_lazy for levels 7-9
+#ifndef LDH_REFILL_MIN_SHALLOW
+#define LDH_REFILL_MIN_SHALLOW 1
+#endif
+constexpr int kRefillMinShallow = LDH_REFILL_MIN_SHALLOW;  // ... and for levels 4-6
 constexpr uint32_t kMatchSteps = LDH_MATCH_STEPS;  // chain steps between two looks at the long paths
 
 // One lane works on one position at a time and walks its chain one candidate per loop

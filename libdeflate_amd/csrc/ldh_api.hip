@@ -418,7 +418,7 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
     HIPCHK(hipFuncSetAttribute((const void *)k_sort_links<true, kSortThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(kSortLdsMaxV)));
     HIPCHK(hipFuncSetAttribute((const void *)k_seg_links, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSegLdsBytes));
-    for (const void *f : {(const void *)k_match_lazy<false, 1, kMatchThreads>, (const void *)k_match_lazy<true, 1, kMatchThreads>,
+    for (const void *f : {(const void *)k_match_lazy<false, kRefillMinShallow, kMatchThreads>, (const void *)k_match_lazy<true, kRefillMinShallow, kMatchThreads>,
                           (const void *)k_match_lazy<false, kRefillMinDeep, kMatchThreads>,
                           (const void *)k_match_lazy<true, kRefillMinDeep, kMatchThreads>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
@@ -489,8 +489,8 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
           // short streams: one tile is the whole stream; small workgroups, LDS sized to the longest stream
           const uint32_t cap = (uint32_t)round_up((size_t)vd + max_in_len + 288 + 16, 16);
           const uint32_t lds = cap + 2 * (uint32_t)(vd + max_in_len + 8);
-          if (vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, 1, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap, 1u);
-          if (!vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, 1, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap, 1u);
+          if (vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinShallow, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap, 1u);
+          if (!vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinShallow, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap, 1u);
           if (vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap, 1u);
           if (!vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep, kMatchThreadsNarrow>), c * tiles, kMatchThreadsNarrow, lds, B, tiles, cap, 1u);
         } else if (tiles) {
@@ -499,8 +499,8 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
           // streams when the batch has workgroups enough without cutting them, else four tiles
           const uint32_t tpw = count >= 1024 ? tiles : (tiles < 4 ? tiles : 4u);
           const uint32_t mruns = (tiles + tpw - 1) / tpw;
-          if (vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, 1, kMatchThreads>), c * mruns, kMatchThreads, kMatchLdsBytes, B, tiles, cap, tpw);
-          if (!vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, 1, kMatchThreads>), c * mruns, kMatchThreads, kMatchLdsBytes, B, tiles, cap, tpw);
+          if (vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinShallow, kMatchThreads>), c * mruns, kMatchThreads, kMatchLdsBytes, B, tiles, cap, tpw);
+          if (!vd && !deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinShallow, kMatchThreads>), c * mruns, kMatchThreads, kMatchLdsBytes, B, tiles, cap, tpw);
           if (vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<true, kRefillMinDeep, kMatchThreads>), c * mruns, kMatchThreads, kMatchLdsBytes, B, tiles, cap, tpw);
           if (!vd && deep) LAUNCH("k_match_lazy", (k_match_lazy<false, kRefillMinDeep, kMatchThreads>), c * mruns, kMatchThreads, kMatchLdsBytes, B, tiles, cap, tpw);
         }
