@@ -1717,9 +1717,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const uint32_t *dg = (const uint32_t *)cbase;
   const uint32_t *ng = (const uint32_t *)(cbase + (size_t)B.nvp * 2 * K);
   const uint16_t *dg16 = (const uint16_t *)cbase;
-  const LevelCfg cfg = level_cfg(B.level);
-  const uint32_t nice = (uint32_t)cfg.nice, max_chain = (uint32_t)cfg.max_chain;
-  const uint32_t max_insert = (uint32_t)cfg.max_lazy;  // max_insert_length for these levels
+  // (the level's parameters as constants -- the list length K stands for the level: 8 = level 1, 16 = level 2 -- so that
+  // tests like `j < max_insert` are decided at compile time instead of by a scalar branch each)
+  constexpr uint32_t nice = K == 8 ? 8u : 18u, max_chain = K == 8 ? 4u : 8u;  // level_cfg(1 / 2)
+  constexpr uint32_t max_insert = K == 8 ? 4u : 5u;                         // max_insert_length (LD:1249-1250)
   const uint32_t nblk = num_blocks(n);
   const unsigned long long below = (1ull << lane) - 1ull;
   for (uint32_t i = lane; i < 1024; i += kWave) s_ins[i] = 0;
@@ -1794,50 +1795,39 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       const unsigned long long special =
           ballot64(valid & ((st1 != ST_DONE) | (m1 & (best1 >= kCandLenCap) & (maxlen_l > kCandLenCap))));
       const uint32_t tok1 = m1 ? tok_match(best1, bd1) : litv;
-      uint32_t cur = 0, nt = 0;
-      while (cur < limit) {
-        unsigned long long vis = 0;
-        uint32_t k = cur;
-        while (k < limit && !((special >> k) & 1ull)) {
-          vis |= 1ull << k;
-          k += (uint32_t)__builtin_amdgcn_readlane((int)len1, (int)k);
-        }
-        if (vis) {  // (uniform)
-          const bool isv = ((vis >> lane) & 1ull) != 0;
-          if (isv) tok[ntok + nt + (uint32_t)__popcll(vis & below)] = tok1;
-          nt += (uint32_t)__popcll(vis);
-          // the bitmap over [c0 + cur, c0 + k): a token's first position always, the others of a match of at most
-          // max_insert_length bytes too (LD:1452-1462); M = those bits relative to c0 (a short match near lane 63
-          // reaches a few bits beyond 64)
-          unsigned long long mlo = vis, mhi = 0;
+      // What a round decides is kept in registers until its end: visF / visR the lanes whose position starts a token
+      // (final lanes the hop came by / lanes resolved on their own), tokv the token of each, R the bitmap bits of the
+      // resolved tokens (relative to c0).  Tokens and bitmap words are written once, behind the walk; a resolution that
+      // must know whether a position of this round is in the chains reads the bits from these masks instead of LDS.
+      // (Storing the tokens and rewriting the bitmap after every stretch of final lanes was some 65 instructions a
+      // stretch, six stretches a round.)
+      // Sj: final lanes whose token is a match short enough for its interior to be inserted and longer than j
+      unsigned long long Sj[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-          for (uint32_t j = 1; j < 6; j++) {
-            if (j < max_insert) {  // (uniform)
-              const unsigned long long bj = ballot64(isv & m1 & (len1 <= max_insert) & (len1 > j));
-              mlo |= bj << j;
-              mhi |= bj >> (64 - j);
-            }
+      for (uint32_t j = 1; j < 6; j++)
+        if (j < max_insert) Sj[j - 1] = ballot64(m1 & (len1 <= max_insert)) & ballot64(len1 > j);  // (uniform test)
+      auto final_bits_lo = [&](unsigned long long vf) {
+        unsigned long long m = vf;
+#pragma unroll
+        for (uint32_t j = 1; j < 6; j++)
+          if (j < max_insert) m |= (vf & Sj[j - 1]) << j;
+        return m;
+      };
+      unsigned long long visF = 0, visR = 0, Rlo = 0, Rhi = 0;
+      uint32_t tokv = tok1;
+      uint32_t cur = 0;
+      while (cur < limit) {
+        {
+          uint32_t k = cur;
+          while (k < limit && !((special >> k) & 1ull)) {
+            visF |= 1ull << k;
+            k += (uint32_t)__builtin_amdgcn_readlane((int)len1, (int)k);
           }
-          const uint32_t first = c0 + cur, last = c0 + k - 1, wi = (first >> 5) + lane;
-          if (wi <= (last >> 5)) {
-            const uint32_t lo = first > wi * 32 ? first - wi * 32 : 0u;
-            const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
-            const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
-            const int32_t rel0 = (int32_t)(wi * 32) - (int32_t)c0;  // bit 0 of this word, relative to c0: -31 ..
-            uint32_t val;
-            if (rel0 < 0)
-              val = (uint32_t)(mlo << (uint32_t)(-rel0));
-            else if (rel0 < 64)
-              val = (uint32_t)(mlo >> (uint32_t)rel0) | (rel0 > 32 ? (uint32_t)(mhi << (uint32_t)(64 - rel0)) : 0u);
-            else
-              val = rel0 < 128 ? (uint32_t)(mhi >> (uint32_t)(rel0 - 64)) : 0u;
-            const uint32_t slot = wi & 1023u;
-            s_ins[slot] = (s_ins[slot] & ~mask) | (val & mask);
-          }
-          lds_order();
           cur = k;
           if (cur >= limit) break;
         }
+        // the positions of this round that are in the chains so far (bit i: position c0 + i; px - c0 < 64)
+        const unsigned long long in_round = final_bits_lo(visF) | Rlo;
         // ---- the lane at `cur` is not final: resolve it now that everything before it is
         const uint32_t px = c0 + cur;  // the position the walk is at
         uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)best1, (int)cur);
@@ -1888,13 +1878,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             const unsigned long long notok = ~ballot64(ok);
             const uint32_t first_bad = (uint32_t)__builtin_ctzll(notok);  // (<= K: lanes K.. are never ok)
             const bool in_chain = lane < first_bad;
-            const bool ins = in_chain && ((s_ins[(q >> 5) & 1023u] >> (q & 31)) & 1u);
+            const uint32_t qr = q - c0;  // (q < px: below 64 when the candidate lies in this round, huge otherwise)
+            const uint32_t wq = qr < 64u ? (uint32_t)(in_round >> (qr & 63u)) : (s_ins[(q >> 5) & 1023u] >> (q & 31));
+            const bool ins = in_chain && (wq & 1u);
             const unsigned long long insm = ballot64(ins);
             const bool sel = ins && (uint32_t)__popcll(insm & below) < dleft;  // LD:1362
             uint32_t L = 0;
             if (first_trip) {  // (uniform)
               L = sel ? Ln : 0u;
             } else if (sel) {
+              // (the compiler sinks each load into the branch that needs it; forcing all four into flight together was
+              // measured: 44.0 ms against 41.4 -- the kernel is bound by what it issues, not by these latencies)
               const uint32_t x0 = gld4(V, q + 3) ^ my0, x1 = gld4(V, q + 7) ^ my1, x2 = gld4(V, q + 11) ^ my2, x3 = gld4(V, q + 15) ^ my3;
               L = 3 + (x0 ? (uint32_t)__builtin_ctz(x0) >> 3
                           : (x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
@@ -1948,23 +1942,43 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         } else {
           t = (uint32_t)__builtin_amdgcn_readlane((int)litv, (int)cur);
         }
-        if (lane == 0) tok[ntok + nt] = t;
-        nt++;
-        {
-          const uint32_t first = px, last = px + len - 1, wi = (first >> 5) + lane;
-          if (wi <= (last >> 5)) {
-            const uint32_t lo = first > wi * 32 ? first - wi * 32 : 0u;
-            const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
-            const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
-            const uint32_t val = interior_on ? mask : (lane == 0 ? 1u << (first & 31) : 0u);
-            const uint32_t slot = wi & 1023u;
-            s_ins[slot] = (s_ins[slot] & ~mask) | val;
-          }
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(tokv) : "s"(t), "s"(cur) : "m0");
+        visR |= 1ull << cur;
+        {  // its bits: the first position always, the others when the match is short enough (len <= 6 then)
+          const unsigned long long m = interior_on ? (1ull << len) - 1ull : 1ull;
+          Rlo |= m << cur;
+          Rhi |= cur ? m >> (64u - cur) : 0ull;
         }
-        lds_order();
         cur += len;
       }
-      ntok += nt;
+      // ---- the round's tokens, in order, and its bitmap words over [c0, c0 + cur)
+      {
+        const unsigned long long vis = visF | visR;
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(vis >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vis, 0));
+        if (__builtin_amdgcn_inverse_ballot_w64(vis)) tok[ntok + before] = tokv;
+        ntok += (uint32_t)__popcll(vis);
+        unsigned long long mlo = final_bits_lo(visF) | Rlo, mhi = Rhi;
+#pragma unroll
+        for (uint32_t j = 1; j < 6; j++)
+          if (j < max_insert) mhi |= (visF & Sj[j - 1]) >> (64 - j);
+        const uint32_t first = c0, last = c0 + cur - 1, wi = (first >> 5) + lane;
+        if (wi <= (last >> 5)) {
+          const uint32_t lo = first > wi * 32 ? first - wi * 32 : 0u;
+          const uint32_t hi = last < wi * 32 + 31 ? last - wi * 32 : 31u;
+          const uint32_t mask = (hi == 31 ? ~0u : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+          const int32_t rel0 = (int32_t)(wi * 32) - (int32_t)c0;  // bit 0 of this word, relative to c0: -31 ..
+          uint32_t val;
+          if (rel0 < 0)
+            val = (uint32_t)(mlo << (uint32_t)(-rel0));
+          else if (rel0 < 64)
+            val = (uint32_t)(mlo >> (uint32_t)rel0) | (rel0 > 32 ? (uint32_t)(mhi << (uint32_t)(64 - rel0)) : 0u);
+          else
+            val = rel0 < 128 ? (uint32_t)(mhi >> (uint32_t)(rel0 - 64)) : 0u;
+          const uint32_t slot = wi & 1023u;
+          s_ins[slot] = (s_ins[slot] & ~mask) | (val & mask);
+        }
+        lds_order();
+      }
       x = c0 + cur;
     }
     if (lane == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = ntok;

@@ -387,6 +387,11 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
   static const int greedy2_max = getenv("LDH_GREEDY2_MAX") ? atoi(getenv("LDH_GREEDY2_MAX")) : 1;
   const bool greedy2 = greedy && level <= greedy2_max && level <= 2 && vd == 0 && !greedy_v1;
   const int candK = level == 1 ? 8 : 16;
+  if (greedy2) {  // k_lz_greedy2<K> has its level's parameters built in
+    const LevelCfg lc = level_cfg(level);
+    if (lc.nice != (candK == 8 ? 8 : 18) || lc.max_chain != (candK == 8 ? 4 : 8) || lc.max_lazy != (candK == 8 ? 4 : 5))
+      return fail(LDH_E_ARG, "k_lz_greedy2: level %d does not match the constants of K = %d", level, candK);
+  }
   const bool want_links = need_lz && (!greedy || greedy2);  // prevd[]: the lazy levels' search and the candidate lists
   // streams beyond the narrow sort's: k_seg_links (segments of 32768 positions sorted inside LDS, any length)
   const bool seg_links = want_links && ((size_t)nvp + kVPad + 15) / 16 * 16 > kSortNarrowMaxLds;
