@@ -1781,7 +1781,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         st = st == ST_RUN ? (more ? (uint32_t)ST_MORE : (uint32_t)ST_DONE) : st;
       };
       eval(valid && p + 3 <= be /* LD:1349 */, c0);
-      const uint32_t best1 = best, bd1 = bd, st1 = st;
+      const uint32_t best1 = best, bd1 = bd, st1 = st, depth1 = depth, lastd1 = lastd;
       // ---- phase 2: the walk over these 64 positions.  The scalar unit only hops from token to token over the lanes
       // whose result is final (one v_readlane + add a token); what each of those tokens needs done -- forming it,
       // storing it, its bits of the bitmap -- is done by the lanes, for all of them at once.  A lane whose result is not
@@ -1843,9 +1843,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           // the position's own list has them (nibbles); candidates of later trips are compared byte by byte.  A trip
           // beyond the first is two dependent fetches (the list, then the candidates' bytes); the list of the NEXT
           // trip is fetched as soon as this trip's last candidate is known, beside the bytes.
+          // A lane that only needs more candidates (its list ran out with the walk still going, none of its entries
+          // inside the round) has had its own list evaluated for good in phase 1: it starts with the list of its last
+          // candidate, with the best match, the depth left and the last distance that phase 1 ended on.  (Two of three
+          // resolutions are of this kind; taking them through the first trip again was a quarter of the kernel.)
           const bool have = lane < (uint32_t)K;
+          const bool go_on = ts == ST_MORE;  // (uniform)
           uint32_t e = 0xFFFFu, Ln = 0;
-          {
+          if (!go_on) {
             uint32_t v = 0, nw = 0;
 #pragma unroll
             for (int i = 0; i < K / 2; i++) {
@@ -1861,10 +1866,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             Ln = ((nw >> (4 * (lane & 7))) & 15u) + 3;
             Ln = Ln > maxlen ? maxlen : Ln;
           }
-          tb = 0, td = 0;
           uint32_t dleft = max_chain, cl = px;
           uint32_t my0 = 0, my1 = 0, my2 = 0, my3 = 0;
           bool first_trip = true;
+          if (go_on) {  // (tb, td: phase 1's)
+            dleft = (uint32_t)__builtin_amdgcn_readlane((int)depth1, (int)cur);
+            cl = px - (uint32_t)__builtin_amdgcn_readlane((int)lastd1, (int)cur);
+            if (have) e = (uint32_t)dg16[(size_t)cl * K + lane];
+            my0 = gld4(V, px + 3), my1 = gld4(V, px + 7), my2 = gld4(V, px + 11), my3 = gld4(V, px + 15);
+            first_trip = false;
+          } else {
+            tb = 0, td = 0;
+          }
           uint32_t e_next = 0xFFFFu;
           for (;;) {
             const uint32_t e_last = (uint32_t)__builtin_amdgcn_readlane((int)e, K - 1);
