@@ -1753,32 +1753,36 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       }
       const uint32_t litv = V[valid ? p : c0];
       // LD:1362-1398 over the list, for the lanes in `act`; candidates at or beyond `final_below` are not final yet
+      // (The walk's state is two lane predicates -- still running, met a candidate that is not final -- kept as wave
+      // masks; the bitmap word is read whether or not the lane still runs: its index is masked into the ring.)
       uint32_t best, bd, st, depth, lastd;
       auto eval = [&](bool act, uint32_t final_below) {
-        best = 0, bd = 0, depth = max_chain, lastd = 0;
-        st = act ? ST_RUN : ST_DONE;
+        best = 0, bd = 0, depth = max_chain;
+        bool run = act, unc = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
           const uint32_t e = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-          const bool run = st == ST_RUN;
           const bool end = e == 0xFFFFu;  // (an entry is never 0xFFFF otherwise: a distance of 32768 has no successor)
           const uint32_t dist = (e & 0x7FFFu) + 1;
           const uint32_t q = p - dist;  // (no dictionary: q >= 0 for every entry phase A wrote)
-          const bool early = run & !end & (q >= final_below);
-          const bool look = run & !end & !early;
-          const uint32_t w = look ? s_ins[(q >> 5) & 1023u] : 0u;
+          const bool live = run & !end;
+          const bool early = live & (q >= final_below);
+          const bool look = live & !early;
+          const uint32_t w = s_ins[(q >> 5) & 1023u];
           const bool ins = look & (((w >> (q & 31)) & 1u) != 0);
           const uint32_t L = ((nb[k >> 3] >> (4 * (k & 7))) & 15u) + 3;
           const bool better = ins & (L > best);  // LD:1385
           bd = better ? dist : bd;
           best = better ? L : best;
           depth -= ins ? 1u : 0u;
-          lastd = look ? dist : lastd;
-          st = run ? (end ? (uint32_t)ST_DONE : (early ? (uint32_t)ST_UNCERTAIN : ((ins & ((best >= nice) | (depth == 0))) ? (uint32_t)ST_DONE : (uint32_t)ST_RUN))) : st;
+          unc = unc | early;
+          run = look & !(ins & ((best >= nice) | (depth == 0)));
         }
-        // the list is used up and the walk still runs: more candidates only if the chain goes on (bit 15 of the last entry)
+        // the list is used up and the walk still runs: more candidates only if the chain goes on (bit 15 of the last
+        // entry); it then goes on from the list's last candidate
         const bool more = (dd[K / 2 - 1] >> 31) != 0;
-        st = st == ST_RUN ? (more ? (uint32_t)ST_MORE : (uint32_t)ST_DONE) : st;
+        lastd = ((dd[K / 2 - 1] >> 16) & 0x7FFFu) + 1;
+        st = unc ? (uint32_t)ST_UNCERTAIN : ((run & more) ? (uint32_t)ST_MORE : (uint32_t)ST_DONE);
       };
       eval(valid && p + 3 <= be /* LD:1349 */, c0);
       const uint32_t best1 = best, bd1 = bd, st1 = st, depth1 = depth, lastd1 = lastd;
