@@ -1822,11 +1822,24 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       uint32_t cur = 0;
       while (cur < limit) {
         {
-          uint32_t k = cur;
-          while (k < limit && !((special >> k) & 1ull)) {
-            visF |= 1ull << k;
-            k += (uint32_t)__builtin_amdgcn_readlane((int)len1, (int)k);
-          }
+          // while (k < limit && !bit(special, k)) { visF |= bit k; k += len1 of lane k; } -- seven instructions a token
+          // written out (the compiler's version shifts and masks 64-bit values: eleven)
+          uint32_t k = cur, hop_t;
+          asm volatile(
+              "s_cmp_lt_u32 %[k], %[lim]\n\t"
+              "s_cbranch_scc0 2f\n"
+              "1:\n\t"
+              "s_bitcmp1_b64 %[sp], %[k]\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              "s_bitset1_b64 %[vf], %[k]\n\t"
+              "v_readlane_b32 %[t], %[len], %[k]\n\t"
+              "s_add_u32 %[k], %[k], %[t]\n\t"
+              "s_cmp_lt_u32 %[k], %[lim]\n\t"
+              "s_cbranch_scc1 1b\n"
+              "2:"
+              : [k] "+s"(k), [vf] "+s"(visF), [t] "=&s"(hop_t)
+              : [sp] "s"(special), [lim] "s"(limit), [len] "v"(len1)
+              : "scc");
           cur = k;
           if (cur >= limit) break;
         }
