@@ -510,12 +510,17 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
         asm volatile("" ::: "memory");
         const unsigned long long below = ballot64(s_tk[lane] != 0) & le_mask;  // (never 0: a token starts at offset 0)
         const uint32_t info = s_tk[63 - __builtin_clzll(below)];
-        uint32_t v = info >> 4;
         // every store of earlier rounds must have landed before a match source among them is read
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if ((lane < n_tot) & ((info >> 31) != 0)) v = out[op + lane - (info & 0xFFFFu)];
-        if (lane < n_tot) out[op + lane] = (uint8_t)v;
+        // (the load inside the store's branch: with the two side by side there is a path, as the compiler sees it, on
+        // which the load is still in flight at the top of the next round, and the wait it puts there for the load's
+        // register also waits for this round's store -- before the decode instead of behind it, at the fence)
+        if (lane < n_tot) {
+          uint32_t v = info >> 4;
+          if ((info >> 31) != 0) v = out[op + lane - (info & 0xFFFFu)];
+          out[op + lane] = (uint8_t)v;
+        }
         op += n_tot;
         rel += k;
         continue;
