@@ -425,6 +425,7 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
   uint32_t lim = 0;                // the input ends `lim` bits after the window's bit 0
   bool have = false;
   const unsigned long long le_mask = (2ull << lane) - 1ull;  // lanes 0..lane
+  uint32_t pend_n = 0, pend_op = 0, pend_v = 0;  // the plain round whose bytes are not stored yet: count, position, bytes
   // (Fencing only in rounds whose match sources were not yet known to have landed was measured: 11.3 ms per GiB against
   // 11.0 with the fence every round; one 128 KiB string 5.05 against 4.81 ms.)
   for (;;) {
@@ -513,14 +514,19 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
         // every store of earlier rounds must have landed before a match source among them is read
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // (the load inside the store's branch: with the two side by side there is a path, as the compiler sees it, on
-        // which the load is still in flight at the top of the next round, and the wait it puts there for the load's
-        // register also waits for this round's store -- before the decode instead of behind it, at the fence)
-        if (lane < n_tot) {
-          uint32_t v = info >> 4;
-          if ((info >> 31) != 0) v = out[op + lane - (info & 0xFFFFu)];
-          out[op + lane] = (uint8_t)v;
-        }
+        // The round's bytes are stored a round later: the match sources are loaded here and waited for only behind
+        // the next round's decode.  A CU serves the vector memory operations of its waves in order (that is why the
+        // fences above cost no wait), so the pending store, issued just before this round's loads, is seen by them;
+        // nothing reads the pending bytes before that (a source inside the round's own output is not a plain round).
+        // (the pending bytes are moved to a register of their own first: that is where the loads are waited for, on
+        // every path; waiting where pend_v is overwritten, behind the store's branch, would wait for the store as well)
+        uint32_t st_v;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(st_v) : "v"(pend_v));
+        if (lane < pend_n) out[pend_op + lane] = (uint8_t)st_v;
+        pend_v = info >> 4;
+        if ((lane < n_tot) & ((info >> 31) != 0)) pend_v = out[op + lane - (info & 0xFFFFu)];
+        pend_n = n_tot;
+        pend_op = op;
         op += n_tot;
         rel += k;
         continue;
@@ -528,6 +534,8 @@ __device__ int decode_block(const LitTab &LT, const DistTab &DT, BitReader &R, O
     }
     break;
     }
+    if (lane < pend_n) out[pend_op + lane] = (uint8_t)pend_v;
+    pend_n = 0;
     // ---- any other round.  Stop events, in the reference's order of checks for one token
     const bool is_len = T.is_len, hard = T.hard;
     const uint32_t mlen = T.mlen, dist = T.dist, tok_bits = T.tok_bits, out_len = T.out_len;
