@@ -23,13 +23,24 @@ __global__ __launch_bounds__(256) void k_histogram(Batch B) {
   const uint32_t ntok = bi->ntok;
   for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < ntok; i += 256) {
-    const uint32_t t = tok[i];
-    if (t & kTokMatch) {
-      atomicAdd(&h[length_code(tok_len(t)).code], 1u);
-      atomicAdd(&h[286 + dist_code(tok_dist(t)).code], 1u);
-    } else {
-      atomicAdd(&h[t], 1u);
+  // (eight loads in flight per thread: one at a time, each waited for, was the kernel's time)
+  for (uint32_t i0 = threadIdx.x; i0 < ntok; i0 += 8 * 256) {
+    uint32_t tv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t i = i0 + k * 256;
+      tv[k] = tok[i < ntok ? i : ntok - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t t = tv[k];
+      if (i0 + k * 256 >= ntok) break;
+      if (t & kTokMatch) {
+        atomicAdd(&h[length_code(tok_len(t)).code], 1u);
+        atomicAdd(&h[286 + dist_code(tok_dist(t)).code], 1u);
+      } else {
+        atomicAdd(&h[t], 1u);
+      }
     }
   }
   __syncthreads();
@@ -698,13 +709,21 @@ __global__ __launch_bounds__(kPackThreads) void k_bitpack(Batch B) {
     const uint32_t ntok = bi->ntok;
     const uint32_t nsym = ntok + 1;  // + EOB
     for (uint32_t r0 = 0; r0 < nsym; r0 += kPackRound) {
+      // (a thread's tokens of the round, all loads in flight together: loaded where each is used, inside its branch,
+      // they were four waits one after the other, each also behind the round before's stores)
+      uint32_t tv[kPackItems];
+#pragma unroll
+      for (int k = 0; k < kPackItems; k++) {
+        const uint32_t i = r0 + tid * kPackItems + k;
+        tv[k] = tok[i < ntok ? i : (ntok ? ntok - 1 : 0u)];  // (a block has a token slot even when it has no token)
+      }
 #pragma unroll
       for (int k = 0; k < kPackItems; k++) {
         const uint32_t i = r0 + tid * kPackItems + k;
         uint64_t v = 0;
         uint32_t l = 0;
         if (i < nsym) {
-          const uint32_t t = i < ntok ? tok[i] : 256u;
+          const uint32_t t = i < ntok ? tv[k] : 256u;
           if (t & kTokMatch) {
             const Code lc = length_code(tok_len(t));
             const Code dc = dist_code(tok_dist(t));
