@@ -1246,6 +1246,17 @@ constexpr uint32_t kParseChunk = 32;
 // chunk each hit different banks
 __device__ inline uint32_t parse_slot(uint32_t j) { return j + (j >> 5); }
 
+#ifdef LDH_PARSE_STAMPS  // diagnostic builds only: shader cycles per phase of a tile (wavefront 0 of every workgroup)
+__device__ unsigned long long g_parse_stamps[16];
+#define LDH_PSTAMP(k_)                                             \
+  {                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    ps_acc[k_] += now_ - ps_t;                                     \
+    ps_t = now_;                                                   \
+  }
+#else
+#define LDH_PSTAMP(k_)
+#endif
 #ifndef LDH_PARSE_WAVES
 #define LDH_PARSE_WAVES 4  // four workgroups per CU (their LDS: 35 KB each)
 #endif
@@ -1276,7 +1287,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
   const uint32_t max_lazy = (uint32_t)level_cfg(B.level).max_lazy;
 
   uint32_t tile_entry = xb0, tok_base = 0;
+#ifdef LDH_PARSE_STAMPS
+  unsigned long long ps_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps_t = __builtin_amdgcn_s_memtime();
+  uint32_t ps_tiles = 0, ps_reps = 0;
+#endif
   for (uint32_t x0 = xb0; x0 <= xb1; x0 += kParseTile) {
+    LDH_PSTAMP(5)
     // ---- stage the tile: one word per position = literal byte | (dist - 1) << 8 | length << 23
     // (8 + 15 + 9 bits), so that step widths and tokens can both be derived from LDS alone.  Half a
     // tile at a time: all loads of a half are issued before any of them is waited for; addresses
@@ -1303,6 +1319,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
       s_tok[parse_slot(kParseTile)] = xe <= xb1 ? (m[xe] >> 16) << 23 : 0u;
     }
     __syncthreads();
+    LDH_PSTAMP(0)
 
     // ---- the walk, by relaxation over chunks.  A lane keeps the 32 step widths of its chunk
     // in registers, so a (re-)walk is straight-line code with no memory access.
@@ -1310,7 +1327,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
     // the block, else 0 (see above)
     const uint32_t cs = x0 + c * kParseChunk;
     const uint32_t clen = cs > xb1 ? 0u : (xb1 + 1 - cs < kParseChunk ? xb1 + 1 - cs : kParseChunk);
-    uint32_t st[kParseChunk];
     uint32_t is_match = 0;  // bit k: position cs + k, if the walk comes by, emits a match
     {
       uint32_t w = s_tok[c * (kParseChunk + 1)];
@@ -1320,26 +1336,38 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
         const uint32_t pl = w >> 23, pd1 = (w >> 8) & 0x7FFFu;
         const uint32_t look = ((pl < max_lazy) & (cs + k + 1 <= xb1)) ? wn >> 23 : 0u;
         const bool mt = ((pl > 3) | ((pl == 3) & (pd1 < 4095u))) & (look <= pl);  // LD:1402-1404
-        st[k] = mt ? pl : 1u;
-        is_match |= mt ? 1u << k : 0u;
+        is_match |= mt ? 1u << k : 0u;  // (positions beyond the block's end were staged as 0: no bit)
         w = wn;
       }
     }
     uint32_t entry = c == 0 ? tile_entry : cs, exit_x = 0, mask = 0;
     bool redo = true;
+    LDH_PSTAMP(1)
     for (;;) {
+#ifdef LDH_PARSE_STAMPS
+      ps_reps++;
+#endif
       if (redo) {
         // (entry >= cs always: it is an exit of a chunk to the left, or the assumed cs)
-        const uint32_t e0 = entry - cs;
-        mask = e0 < clen ? 1u << e0 : 0u;
+        // The walk hops from match to match: between two of them every position is a literal and is visited, so a
+        // hop is "the next bit of is_match at or above k", a run of mask bits, and the match's length from LDS --
+        // three or four hops a chunk on text, where stepping through all 32 positions (their widths in 32 registers)
+        // was 160 dependent instructions a walk and a third of the kernel.
+        uint32_t k = entry - cs;
+        mask = 0;
         exit_x = entry;
-#pragma unroll
-        for (int k = 0; k < (int)kParseChunk; k++) {
-          const bool on = (mask >> k) & 1;
-          const uint32_t nx = k + st[k];
-          const bool inside = nx < clen;
-          mask |= (on & inside) ? 1u << (nx & 31) : 0u;
-          exit_x = (on & !inside) ? cs + nx : exit_x;
+        while (k < clen) {
+          const uint32_t mm = is_match >> k;
+          if (mm == 0) {  // literals to the chunk's end
+            mask |= (clen >= 32 ? ~0u : (1u << clen) - 1u) & ~((1u << k) - 1u);
+            exit_x = cs + clen;
+            break;
+          }
+          const uint32_t j = k + (uint32_t)__builtin_ctz(mm);  // the next match the walk meets
+          mask |= ((2u << j) - 1u) & ~((1u << k) - 1u);           // positions k .. j
+          const uint32_t nx = j + (s_tok[c * (kParseChunk + 1) + j] >> 23);
+          exit_x = cs + nx;  // (stands when the match leaves the chunk)
+          k = nx;
         }
       }
       // entry of chunk c = the largest exit to its left (exits of the true walk never
@@ -1363,9 +1391,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
       if (!__syncthreads_or(redo)) break;
     }
 
+    LDH_PSTAMP(2)
     // ---- emit the visited positions' tokens
     const uint32_t cnt = __popc(mask);
     scan256_exclusive(cnt, c, s_off, s_tot);
+    LDH_PSTAMP(3)
     uint32_t o = tok_base + s_off[c];
     while (mask) {
       const uint32_t bit = (uint32_t)__builtin_ctz(mask);
@@ -1379,9 +1409,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
       s_tile_exit = exit_x > entry ? exit_x : entry;
     }
     __syncthreads();
+    LDH_PSTAMP(4)
+#ifdef LDH_PARSE_STAMPS
+    ps_tiles++;
+#endif
     tok_base += s_tile_tot;
     tile_entry = s_tile_exit;
   }
+#ifdef LDH_PARSE_STAMPS
+  if (c == 0) {
+    for (int i = 0; i < 8; i++) atomicAdd(&g_parse_stamps[i], ps_acc[i]);
+    atomicAdd(&g_parse_stamps[14], (unsigned long long)ps_reps);
+    atomicAdd(&g_parse_stamps[15], (unsigned long long)ps_tiles);
+  }
+#endif
   if (c == 0) B.blocks[(size_t)s * B.max_blocks + b].ntok = tok_base;
 }
 

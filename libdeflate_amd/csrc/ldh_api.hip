@@ -1941,6 +1941,17 @@ int ldh_debug_wide_stamps(unsigned long long *dst, int reset) {
   return 0;
 }
 #endif
+#ifdef LDH_PARSE_STAMPS  // diagnostic builds only (not declared in the header)
+int ldh_debug_parse_stamps(unsigned long long *dst, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(ldh::g_parse_stamps), 16 * 8);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(ldh::g_parse_stamps), z, 16 * 8);
+  }
+  return 0;
+}
+#endif
 int ldh_debug_fetch(int what, size_t stream, void *dst, size_t cap_bytes, size_t *got_bytes) {
   CTX_ENTER(cx);
   if (!cx.have_last || stream >= cx.last.count) return fail(LDH_E_ARG, "no such stream in the last batch");
