@@ -1291,33 +1291,48 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
   unsigned long long ps_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps_t = __builtin_amdgcn_s_memtime();
   uint32_t ps_tiles = 0, ps_reps = 0;
 #endif
+  // A thread stages four consecutive positions at a time: one 16-byte load of the matches and one 4-byte load of the
+  // bytes, neither aligned beyond what the arrays are (a sixth of the load instructions of one position per thread and
+  // load; reading up to three entries past the block's end stays inside the arrays' padding).  The loads of a tile are
+  // issued before the tile before it stores its tokens: memory operations complete in the order they were issued, so
+  // loads behind those scattered stores would wait for every one of them.
+  typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef uint32_t u32_a1 __attribute__((aligned(1)));
+  constexpr int kGroups = kParseRounds / 4;  // groups of 4 * THREADS positions
+  u32x4_a4 mm[kGroups];
+  uint32_t bb[kGroups], ahead = 0;  // ahead: the match at the first position of the tile after (only its length is looked at)
+  auto fetch = [&](uint32_t x0_) {
+    {
+      const uint32_t xe = x0_ + kParseTile;
+      ahead = m[xe <= xb1 ? xe : xb1];
+    }
+#pragma unroll
+    for (int r = 0; r < kGroups; r++) {
+      const uint32_t x = x0_ + r * 4 * kParseThreads + 4 * c;
+      const uint32_t xc = x <= xb1 ? x : xb1;
+      mm[r] = *(const u32x4_a4 *)(m + xc);
+      bb[r] = *(const u32_a1 *)(Vd + xc);
+    }
+  };
+  fetch(xb0);
   for (uint32_t x0 = xb0; x0 <= xb1; x0 += kParseTile) {
     LDH_PSTAMP(5)
     // ---- stage the tile: one word per position = literal byte | (dist - 1) << 8 | length << 23
     // (8 + 15 + 9 bits), so that step widths and tokens can both be derived from LDS alone.  Half a
     // tile at a time: all loads of a half are issued before any of them is waited for; addresses
     // are clamped rather than branched around.
+    // ---- (the tile's words were loaded before the tile before it wrote its tokens out: see `fetch` below)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      uint32_t mm[kParseRounds / 2], bb[kParseRounds / 2];
+    for (int r = 0; r < kGroups; r++) {
+      const uint32_t j0 = r * 4 * kParseThreads + 4 * c;
 #pragma unroll
-      for (int r = 0; r < kParseRounds / 2; r++) {
-        const uint32_t x = x0 + (h * (kParseRounds / 2) + r) * kParseThreads + c;
-        const uint32_t xc = x <= xb1 ? x : xb1;
-        mm[r] = m[xc];
-        bb[r] = Vd[xc];
-      }
-#pragma unroll
-      for (int r = 0; r < kParseRounds / 2; r++) {
-        const uint32_t j = (h * (kParseRounds / 2) + r) * kParseThreads + c;
-        const uint32_t w = bb[r] | (((mm[r] - 1u) & 0x7FFFu) << 8) | ((mm[r] >> 16) << 23);
-        s_tok[parse_slot(j)] = x0 + j <= xb1 ? w : 0u;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t mk = mm[r][k];
+        const uint32_t w = ((bb[r] >> (8 * k)) & 0xFFu) | (((mk - 1u) & 0x7FFFu) << 8) | ((mk >> 16) << 23);
+        s_tok[parse_slot(j0 + k)] = x0 + j0 + k <= xb1 ? w : 0u;
       }
     }
-    if (c == 0) {  // the first position of the next tile: only its length is looked at
-      const uint32_t xe = x0 + kParseTile;
-      s_tok[parse_slot(kParseTile)] = xe <= xb1 ? (m[xe] >> 16) << 23 : 0u;
-    }
+    if (c == 0) s_tok[parse_slot(kParseTile)] = x0 + kParseTile <= xb1 ? (ahead >> 16) << 23 : 0u;
     __syncthreads();
     LDH_PSTAMP(0)
 
@@ -1392,6 +1407,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
     }
 
     LDH_PSTAMP(2)
+    if (x0 + kParseTile <= xb1) fetch(x0 + kParseTile);  // (uniform)
     // ---- emit the visited positions' tokens
     const uint32_t cnt = __popc(mask);
     scan256_exclusive(cnt, c, s_off, s_tot);
