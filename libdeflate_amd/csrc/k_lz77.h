@@ -71,15 +71,10 @@ constexpr uint32_t kSortNarrowMaxLds = LDH_SORT_NARROW_MAX;  // streams up to ab
 // exclusive scan of 256 values held by threads 0..255 (one value each); result in out[256]
 __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *out, uint32_t *wave_tot) {
   const uint32_t lane = tid & 63, wave = tid >> 6;
-  uint32_t inc = val;
-  if (tid < 256) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t t = __shfl_up(inc, off);
-      if (lane >= (uint32_t)off) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-  }
+  // (DPP row shifts and broadcasts, six dependent vector instructions: the __shfl_up form is six trips through the
+  // LDS crossbar, each waited for)
+  const uint32_t inc = wave_inclusive_sum(val);
+  if (tid < 256 && lane == 63) wave_tot[wave] = inc;
   __syncthreads();
   if (tid < 256) {
     uint32_t base = 0;
@@ -87,6 +82,22 @@ __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *o
     out[tid] = base + inc - val;
   }
   __syncthreads();
+}
+
+// max(x, x moved along by a DPP control); lanes without a source lane keep x (values are unsigned)
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_max(uint32_t x) {
+  const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+  return y > x ? y : x;
+}
+__device__ inline uint32_t wave_inclusive_max(uint32_t x) {
+  x = dpp_max<0x111, 0xF>(x);  // row_shr:1
+  x = dpp_max<0x112, 0xF>(x);  // row_shr:2
+  x = dpp_max<0x114, 0xF>(x);  // row_shr:4
+  x = dpp_max<0x118, 0xF>(x);  // row_shr:8   -> maxima within rows of 16
+  x = dpp_max<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_max<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
 }
 
 // V_LDS: the bytes being sorted also live in LDS (up to kSortLdsMaxV of them), so the
@@ -1389,18 +1400,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LDH_PAR
       // decrease).  A chunk the walk only passes through (or an empty one) contributes
       // nothing of its own, so that a wrong value to its left is gone the moment its source
       // is corrected instead of being handed on one chunk per repeat.
-      uint32_t inc = mask ? exit_x : 0u;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= (uint32_t)off && t > inc) inc = t;
-      }
+      const uint32_t inc = wave_inclusive_max(mask ? exit_x : 0u);
       if (lane == 63) s_wmax[wave] = inc;
       __syncthreads();
       uint32_t e = tile_entry;
       for (uint32_t w = 0; w < wave; w++) e = s_wmax[w] > e ? s_wmax[w] : e;
-      const uint32_t left = __shfl_up(inc, 1);
-      if (lane > 0 && left > e) e = left;
+      // (wave_shr:1 -- the lane to the left across the rows of 16; lane 0 gets 0)
+      const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xF, 0xF, false);
+      if (left > e) e = left;
       redo = e != entry;
       entry = e;
       if (!__syncthreads_or(redo)) break;
