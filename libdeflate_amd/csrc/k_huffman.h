@@ -536,12 +536,7 @@ __device__ inline void pack_round(Packer &P, const uint64_t *val, const uint32_t
   uint32_t mine = 0;
 #pragma unroll
   for (int k = 0; k < kPackItems; k++) mine += nb[k];
-  uint32_t inc = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(inc, off);
-    if (lane >= (uint32_t)off) inc += t;
-  }
+  const uint32_t inc = wave_inclusive_sum(mine);
   if (lane == 63) P.scan[wave] = inc;
   __syncthreads();
   uint32_t base = 0, tot = 0;

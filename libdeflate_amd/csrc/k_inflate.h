@@ -653,21 +653,6 @@ __device__ inline void lds_barrier() {  // LDS only: stores and loads of the out
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// x + (x moved along by a DPP control; lanes without a source lane add 0)
-template <int CTRL, int ROW_MASK>
-__device__ inline uint32_t dpp_add(uint32_t x) {
-  return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ inline uint32_t wave_inclusive_sum(uint32_t x) {
-  x = dpp_add<0x111, 0xF>(x);  // row_shr:1
-  x = dpp_add<0x112, 0xF>(x);  // row_shr:2
-  x = dpp_add<0x114, 0xF>(x);  // row_shr:4
-  x = dpp_add<0x118, 0xF>(x);  // row_shr:8   -> sums within rows of 16
-  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
-  x = dpp_add<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
-  return x;
-}
-
 #ifdef LDH_WIDE_STAMPS  // diagnostic builds only: shader cycles per phase of a round (workgroup 0, wavefront 0)
 __device__ unsigned long long g_wide_stamps[16];
 #define LDH_STAMP(k_)                                              \

@@ -84,22 +84,6 @@ __device__ inline void scan256_exclusive(uint32_t val, uint32_t tid, uint32_t *o
   __syncthreads();
 }
 
-// max(x, x moved along by a DPP control); lanes without a source lane keep x (values are unsigned)
-template <int CTRL, int ROW_MASK>
-__device__ inline uint32_t dpp_max(uint32_t x) {
-  const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
-  return y > x ? y : x;
-}
-__device__ inline uint32_t wave_inclusive_max(uint32_t x) {
-  x = dpp_max<0x111, 0xF>(x);  // row_shr:1
-  x = dpp_max<0x112, 0xF>(x);  // row_shr:2
-  x = dpp_max<0x114, 0xF>(x);  // row_shr:4
-  x = dpp_max<0x118, 0xF>(x);  // row_shr:8   -> maxima within rows of 16
-  x = dpp_max<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
-  x = dpp_max<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
-  return x;
-}
-
 // V_LDS: the bytes being sorted also live in LDS (up to kSortLdsMaxV of them), so the
 // per-element key fetches of passes 1-2 and the trigram compares of the link pass are LDS
 // byte reads instead of fully divergent global loads (which bound the first version).
@@ -591,11 +575,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
           }
           uint32_t inc = tot;
           if (tid < 256) {
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-              const uint32_t t = __shfl_up(inc, off);
-              if (lane >= (uint32_t)off) inc += t;
-            }
+            inc = wave_inclusive_sum(inc);
             if (lane == 63) s_tot[wave] = inc;
           }
           __syncthreads();
@@ -657,7 +637,8 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
       const bool valid = r < m;
       const uint32_t v = valid ? (uint32_t)E[r] : 0u;
       const uint32_t k = valid ? seg_key(Vw, v) : 0xFFFFFFFFu;
-      const uint32_t pv_in = __shfl_up(v, 1), pk_in = __shfl_up(k, 1), nk_in = __shfl_down(k, 1);
+      // (the lanes beside this one by DPP wave shifts, not through the LDS crossbar; lanes 0 / 63 take the rows' values)
+      const uint32_t pv_in = wave_shr1(v), pk_in = wave_shr1(k), nk_in = wave_shl1(k);
       const uint32_t pv_row = row ? (uint32_t)rowP1[row - 1] : 0u, pk_row = row ? rowK1[row - 1] : 0xFFFFFFFEu;
       const uint32_t nk_row = row + 1 < kSegItems * kSegWaves ? rowK0[row + 1] : 0xFFFFFFFEu;
       const uint32_t pv = lane == 0 ? pv_row : pv_in, pk = lane == 0 ? pk_row : pk_in, nk = lane == 63 ? nk_row : nk_in;
@@ -693,11 +674,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
       if (want_list && tid < kSegItems * kSegWaves) {
         val = s_lcnt[tid];
         inc = val;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t t = __shfl_up(inc, off);
-          if (lane >= (uint32_t)off) inc += t;
-        }
+        inc = wave_inclusive_sum(inc);
         if (lane == 63) s_tot[wave] = inc;
       }
       __syncthreads();

@@ -158,4 +158,39 @@ __device__ inline uint32_t stream_len(const Batch &B, uint32_t s) {
   return n > B.max_len ? B.max_len : (uint32_t)n;
 }
 
+// x + (x moved along by a DPP control; lanes without a source lane add 0)
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_add(uint32_t x) {
+  return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ inline uint32_t wave_inclusive_sum(uint32_t x) {
+  x = dpp_add<0x111, 0xF>(x);  // row_shr:1
+  x = dpp_add<0x112, 0xF>(x);  // row_shr:2
+  x = dpp_add<0x114, 0xF>(x);  // row_shr:4
+  x = dpp_add<0x118, 0xF>(x);  // row_shr:8   -> sums within rows of 16
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_add<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
+// max(x, x moved along by a DPP control); lanes without a source lane keep x (values are unsigned)
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_max(uint32_t x) {
+  const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+  return y > x ? y : x;
+}
+__device__ inline uint32_t wave_inclusive_max(uint32_t x) {
+  x = dpp_max<0x111, 0xF>(x);  // row_shr:1
+  x = dpp_max<0x112, 0xF>(x);  // row_shr:2
+  x = dpp_max<0x114, 0xF>(x);  // row_shr:4
+  x = dpp_max<0x118, 0xF>(x);  // row_shr:8   -> maxima within rows of 16
+  x = dpp_max<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_max<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
+// the value of the lane to the left / right (lane 0 / lane 63 get 0): DPP wave shifts
+__device__ inline uint32_t wave_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, false); }
+__device__ inline uint32_t wave_shl1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, false); }
+
 }  // namespace ldh
