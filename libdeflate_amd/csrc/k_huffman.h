@@ -189,11 +189,9 @@ __device__ int huff_build(HuffScratch &S, int nsym, int max_bitlen, uint32_t lan
         if (sy > max_nz) max_nz = sy;
       }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      over += __shfl_xor(over, o);
-      const int m = __shfl_xor(max_nz, o);
-      max_nz = m > max_nz ? m : max_nz;
-    }
+    // (DPP scans, the totals read from lane 63: butterflies of __shfl_xor are trips through the LDS crossbar)
+    over = (int)__builtin_amdgcn_readlane((int)wave_inclusive_sum((uint32_t)over), 63);
+    max_nz = (int)__builtin_amdgcn_readlane((int)wave_inclusive_max((uint32_t)(max_nz + 1)), 63) - 1;
     __syncthreads();
     if (over > 0 && lane == 0) {  // LD:1057-1079
       int overflow = over, bitlen, index = 0;
@@ -368,11 +366,10 @@ __global__ __launch_bounds__(kWave) void k_huffman(Batch B) {
     rle_bits_extra = c * (S.len[lane] + eb);
   }
   // wave reductions
-  for (int off = 32; off > 0; off >>= 1) {
-    dyn += __shfl_down(dyn, off);
-    fix += __shfl_down(fix, off);
-    rle_bits_extra += __shfl_down(rle_bits_extra, off);
-  }
+  // (a block's bit counts stay below 2^32; DPP scans, the totals read from lane 63)
+  dyn = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum((uint32_t)dyn), 63);
+  fix = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum((uint32_t)fix), 63);
+  rle_bits_extra = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(rle_bits_extra), 63);
   if (lane == 0) {
     const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = 0;
