@@ -405,14 +405,13 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
   const uint32_t *Vw = (const uint32_t *)seg_lds;
   uint16_t *E = (uint16_t *)(seg_lds + kSegLdsV);
   __shared__ uint16_t s_cnt[kSegWaves][256];
-  __shared__ uint16_t s_pre[kSegWaves][256];
+  __shared__ __attribute__((aligned(16))) uint16_t s_pre[kSegWaves][256];
   __shared__ uint32_t s_tot[16];
   __shared__ uint32_t s_top;
   __shared__ uint32_t s_lcnt[kSegItems * kSegWaves];  // list entries per (row of 1024, wave), then where they go
   __shared__ uint32_t sK[kSegPiece];  // a piece of the previous segment's list
   __shared__ uint16_t sP[kSegPiece];
-  __shared__ uint32_t qk[kSegWaves][kSegQueue];  // look-ups waiting for a full row, per wave
-  __shared__ uint16_t qv[kSegWaves][kSegQueue];
+  __shared__ uint16_t qv[kSegWaves][kSegQueue];  // look-ups (positions) waiting for a full row, per wave
 
   const uint32_t s = blockIdx.x / runs, run = blockIdx.x % runs;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -617,8 +616,11 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
 #ifdef LDH_SEG_STOP
     if (LDH_SEG_STOP <= 4) continue;
 #endif
-    uint32_t *rowK0 = &qk[0][0], *rowK1 = &qk[kSegWaves / 2][0];  // trigram of a row's first / last element
-    uint16_t *rowP1 = &qv[0][0];                                  // position of its last element
+    // (in s_pre's space, idle between the passes and the next segment's: the look-ups below read the rows' trigram
+    // ranges again, when the queues are in use)
+    static_assert(sizeof(s_pre) >= kSegItems * kSegWaves * (4 + 4 + 2), "row tables in s_pre");
+    uint32_t *rowK0 = (uint32_t *)&s_pre[0][0], *rowK1 = rowK0 + kSegItems * kSegWaves;  // trigram of a row's first / last element
+    uint16_t *rowP1 = (uint16_t *)(rowK1 + kSegItems * kSegWaves);                       // position of its last element
     if (tid < kSegItems * kSegWaves) {
       const uint32_t r0 = tid * 64, r1 = r0 + 63;
       rowK0[tid] = r0 < m ? seg_key(Vw, (uint32_t)E[r0]) : 0xFFFFFFFEu;
@@ -711,17 +713,49 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
 #pragma unroll 1
       for (uint32_t p0 = 0; p0 < nprev; p0 += kSegPiece) {
         const uint32_t pc = nprev - p0 < kSegPiece ? nprev - p0 : kSegPiece;
-        for (uint32_t i = tid; i < pc; i += kSegThreads) {
-          sK[i] = prevK[p0 + i];
-          sP[i] = prevP[p0 + i];
+        {  // (all of a thread's loads in flight together: in a loop, each trip waited for its own)
+          constexpr int kPer = kSegPiece / kSegThreads;
+          uint32_t kk[kPer], pp[kPer];
+          uint32_t tl = t_;
+          asm volatile("" : "+v"(tl));
+#pragma unroll
+          for (int r = 0; r < kPer; r++) {
+            const uint32_t i = tl + r * kSegThreads, ic = i < pc ? i : pc - 1;
+            kk[r] = prevK[p0 + ic];
+            pp[r] = prevP[p0 + ic];
+          }
+#pragma unroll
+          for (int r = 0; r < kPer; r++) {
+            const uint32_t i = tl + r * kSegThreads;
+            if (i < pc) {
+              sK[i] = kk[r];
+              sP[i] = (uint16_t)pp[r];
+            }
+          }
         }
         __syncthreads();
         const uint32_t kmin = sK[0], kmax = sK[pc - 1];
         // one search per lane: the first occurrences of a wave are gathered in its queue until 64 wait
+        // (The queue holds positions only; the trigram is read here, by 64 lanes at once, not in the gathering loop,
+        // where it was a dependent LDS round trip per row.  The search narrows by quarters: three independent reads a
+        // step, seven steps for a piece of 4096 instead of twelve dependent ones.)
         auto search = [&](uint32_t wq, uint32_t at, bool act) {
-          const uint32_t k = act ? qk[wq][at] : 0u, v = act ? (uint32_t)qv[wq][at] : 0u;
+#if defined(LDH_SEG_STOP) && LDH_SEG_STOP == 6  // profiling builds only: everything but the searches themselves
+          return;
+#endif
+          const uint32_t v = act ? (uint32_t)qv[wq][at] : 0u;
+          const uint32_t k = seg_key(Vw, v);
           uint32_t b = 0, len = pc;
-          while (len > 1) {  // (uniform: pc is)
+          while (len > 3) {  // (uniform: pc is)
+            const uint32_t q = len >> 2;
+            const uint32_t a1 = sK[b + q], a2 = sK[b + 2 * q], a3 = sK[b + 3 * q];
+            uint32_t adv = a1 <= k ? q : 0u;
+            adv = a2 <= k ? 2 * q : adv;
+            adv = a3 <= k ? 3 * q : adv;
+            b += adv;
+            len -= 3 * q;  // (the last quarter's length: at least as long as the others, and still inside the piece)
+          }
+          while (len > 1) {
             const uint32_t half = len >> 1;
             if (sK[b + half] <= k) b += half;
             len -= half;
@@ -731,7 +765,20 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
             if (u >= v) E[v] = (uint16_t)(kSegG + v - u);  // distance <= 32768
           }
         };
+        // (the elements are in sorted order: a row whose trigrams lie outside the piece's has nothing to look up in it.
+        // Lane j tests row j of this wave; the rows to look at are then a wave-uniform mask.)
+        uint32_t rows_in;
+        {
+          uint32_t tq = t_;
+          asm volatile("" : "+v"(tq));
+          const uint32_t jr = tq & 31, wq = tq >> 6;
+          const bool in = !(rowK1[jr * kSegWaves + wq] < kmin || rowK0[jr * kSegWaves + wq] > kmax);
+          rows_in = (uint32_t)__builtin_amdgcn_ballot_w64(in);
+        }
         uint32_t cnt = 0;
+#if defined(LDH_SEG_STOP) && LDH_SEG_STOP == 7  // profiling builds only: the pieces' staging and barriers alone
+        rows_in = 0;
+#endif
 #pragma unroll
         for (int j = 0; j < kSegItems; j++) {
           // (thread index opaque per element: the queue addresses derived from it are two instructions
@@ -739,15 +786,14 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_links(Batch B, uint32_t run
           uint32_t tq = t_;
           asm volatile("" : "+v"(tq));
           const uint32_t lq = tq & 63, wq = tq >> 6;
-          const bool f0 = ((res[j] >> 30) & 1u) != 0;
-          if (!__builtin_amdgcn_ballot_w64(f0)) continue;
-          const uint32_t kj = f0 ? seg_key(Vw, res[j] & 0x7FFFu) : 0u;
-          const bool f = f0 && kj >= kmin && kj <= kmax;
+          if (!((rows_in >> j) & 1u)) continue;
+          // (every first occurrence of a row that touches the piece's range: the few whose trigram lies outside it are
+          // looked up in vain, which costs less than reading every trigram here to tell)
+          const bool f = ((res[j] >> 30) & 1u) != 0;
           const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
           if (bal) {
             if (f) {
               const uint32_t slot = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-              qk[wq][slot] = kj;
               qv[wq][slot] = (uint16_t)(res[j] & 0x7FFFu);
             }
             cnt += (uint32_t)__popcll(bal);
