@@ -68,7 +68,7 @@ struct PinBuf {
 // one piece in flight of the host-pointer pipelines (see below)
 struct Slot {
   PinBuf pin_in, pin_off, pin_out, pin_small;
-  DevBuf d_in, d_off, d_out, d_len, d_a8, d_a32a, d_a32b;
+  DevBuf d_in, d_off, d_out, d_len, d_a8, d_a32a, d_a32b, d_scr;  // d_scr: a piece's zlib trailer values and Adler-32 sums
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
   size_t w = 0;  // row width of the result copy in flight
 };
@@ -88,12 +88,12 @@ struct Pending {
 struct Ctx {
   int device = -1;
   std::mutex mu;
-  hipStream_t stream = nullptr, s_in = nullptr, s_out = nullptr;
+  hipStream_t stream = nullptr, s_in = nullptr, s_out = nullptr, s_k2 = nullptr;  // s_k2: every second inflate piece's kernels
   // workspace (grow-only)
   DevBuf vbuf, prevd, bufA, bufB, bufC, blocks, adler, misc32a, misc32b;
   // staging for the host-pointer entry points
   DevBuf h_in, h_off, h_out, h_len, h_aux8, h_aux32a, h_aux32b, codec_tmp;
-  Slot slot[3];
+  Slot slot[5];  // (compress pipelines two pieces; inflate keeps up to three in flight, see decompress_batch_on)
   uint32_t *flags = nullptr;    // [0] streams longer than max_in_len since the last ldh_sync (k_plan)
   uint32_t *flags_host = nullptr;  // pinned word ldh_sync reads flags[0] into, on cx.stream
   uint32_t *noalloc = nullptr;  // this device's copy of `scratch`
@@ -555,13 +555,15 @@ int compress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, 
 int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                           size_t in_stride, size_t count, int fmt,
                           const ldh_dict *dict, uint8_t *d_out, size_t out_stride, uint32_t *d_out_len,
-                          uint32_t *d_bytes_left, int32_t *d_status, uint32_t *scratch2 = nullptr) {
+                          uint32_t *d_bytes_left, int32_t *d_status, uint32_t *scratch2 = nullptr,
+                          uint32_t *actual2 = nullptr, int force_waves = 0) {
   if (count == 0) return 0;
   if (fmt != 0 && fmt != 1) return fail(LDH_E_ARG, "bad fmt %d", fmt);
   if (out_stride % 16 != 0) return fail(LDH_E_ARG, "out_stride must be a multiple of 16");
   // zlib trailer values read by k_inflate / Adler-32 sums of the results: library workspace, or (the
   // no-allocation entry point) the two halves of the caller-independent static scratch
-  uint32_t *expect = scratch2, *actual = scratch2 ? scratch2 + kNoAllocMaxStreams : nullptr;
+  // (actual2: the caller's own second array -- the host path's pieces, which run side by side, each bring theirs)
+  uint32_t *expect = scratch2, *actual = actual2 ? actual2 : (scratch2 ? scratch2 + kNoAllocMaxStreams : nullptr);
   if (!scratch2) {
     if (int rc = ensure(cx.misc32a, count * 4 + 64)) return rc;
     if (int rc = ensure(cx.misc32b, count * 4 + 64)) return rc;
@@ -597,7 +599,7 @@ int decompress_dev_locked(Ctx &cx, const uint8_t *d_in, const uint64_t *d_in_off
   static const int wide4_max = getenv("LDH_INFLATE_WIDE4_MAX") ? atoi(getenv("LDH_INFLATE_WIDE4_MAX")) : 1025;
   static const int wide8_max = getenv("LDH_INFLATE_WIDE8_MAX") ? atoi(getenv("LDH_INFLATE_WIDE8_MAX")) : 513;
   const char *force = getenv("LDH_INFLATE_WAVES");
-  const int waves = force ? atoi(force) : (count < (size_t)wide8_max ? 8 : (count < (size_t)wide4_max ? 4 : 1));
+  const int waves = force ? atoi(force) : (force_waves ? force_waves : (count < (size_t)wide8_max ? 8 : (count < (size_t)wide4_max ? 4 : 1)));
   if (waves == 8)
     LAUNCH("k_inflate", k_inflate_wide8, (uint32_t)count, 8 * kWave, 0, A);
   else if (waves == 2)
@@ -677,6 +679,7 @@ int pipeline_init(Ctx &cx) {
   if (cx.s_in) return 0;
   HIPCHK(hipStreamCreateWithFlags(&cx.s_in, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&cx.s_out, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&cx.s_k2, hipStreamNonBlocking));
   for (Slot &sl : cx.slot) {
     HIPCHK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
@@ -692,7 +695,7 @@ void pipeline_free(Ctx &cx) {
       b->p = nullptr;
       b->cap = 0;
     }
-    for (DevBuf *b : {&sl.d_in, &sl.d_off, &sl.d_out, &sl.d_len, &sl.d_a8, &sl.d_a32a, &sl.d_a32b}) {
+    for (DevBuf *b : {&sl.d_in, &sl.d_off, &sl.d_out, &sl.d_len, &sl.d_a8, &sl.d_a32a, &sl.d_a32b, &sl.d_scr}) {
       if (b->p) hipFree(b->p);
       b->p = nullptr;
       b->cap = 0;
@@ -704,11 +707,20 @@ void pipeline_free(Ctx &cx) {
   }
   if (cx.s_in) hipStreamDestroy(cx.s_in);
   if (cx.s_out) hipStreamDestroy(cx.s_out);
-  cx.s_in = cx.s_out = nullptr;
+  if (cx.s_k2) hipStreamDestroy(cx.s_k2);
+  cx.s_in = cx.s_out = cx.s_k2 = nullptr;
 }
 
 // an entry point that returns early (an error) must not leave copies or kernels in flight on
 // the slots the next call will reuse
+// the context's kernel stream replaced for a scope (LAUNCH and the profiler's events follow cx.stream)
+struct StreamSwap {
+  Ctx &cx;
+  hipStream_t keep;
+  StreamSwap(Ctx &c, hipStream_t s) : cx(c), keep(c.stream) { cx.stream = s; }
+  void restore() { cx.stream = keep; }
+  ~StreamSwap() { restore(); }
+};
 struct DrainGuard {
   bool clean = false;
   ~DrainGuard() {
@@ -1388,6 +1400,8 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
   struct Piece {
     size_t first, last;
   };
+  constexpr size_t kInflateSlots = 5, kInflateAhead = 3;  // (a slot is free again two pieces before it is needed)
+  static_assert(sizeof(cx.slot) / sizeof(cx.slot[0]) >= kInflateSlots, "slots");
   std::vector<Piece> pieces;
   const size_t piece = inflate_piece_bytes(count * out_stride);
   for (size_t i = 0; i < count;) {
@@ -1397,7 +1411,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     i = j;
   }
   auto start_out = [&](size_t k) -> int {  // piece k is done on the device: start copying its results out
-    Slot &sl = cx.slot[k % 3];
+    Slot &sl = cx.slot[k % kInflateSlots];
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first;
     tr.lap(5);
@@ -1434,7 +1448,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     return 0;
   };
   auto scatter = [&](size_t k) -> int {  // results of piece k from pinned memory to the caller's slots
-    Slot &sl = cx.slot[k % 3];
+    Slot &sl = cx.slot[k % kInflateSlots];
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first, w = sl.w;
     if (!w) return 0;
@@ -1454,7 +1468,7 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     return 0;
   };
   for (size_t k = 0; k < pieces.size(); k++) {
-    Slot &sl = cx.slot[k % 3];  // (its last user, piece k-3, was scattered before piece k-1 was enqueued)
+    Slot &sl = cx.slot[k % kInflateSlots];  // (its last user, piece k-5, was scattered before piece k-1 was enqueued)
     const Piece &pc = pieces[k];
     const size_t gc = pc.last - pc.first;
     const uint64_t base = in_off[pc.first], tot = in_off[pc.last] - base;
@@ -1480,28 +1494,40 @@ static int decompress_batch_on(Ctx *on, const uint8_t *in_base, const uint64_t *
     if (tot) HIPCHK(hipMemcpyAsync(sl.d_in.p, src, tot, hipMemcpyHostToDevice, cx.s_in));
     HIPCHK(hipMemcpyAsync(sl.d_off.p, sl.pin_off.p, (gc + 1) * 8, hipMemcpyHostToDevice, cx.s_in));
     HIPCHK(hipEventRecord(sl.ev_in, cx.s_in));
+    // Neighbouring pieces' kernels run side by side, on two streams, one wavefront per stream: a piece of one or two
+    // thousand streams is bound by what one stream's decoder waits for, not by what the chip can issue (2048 streams
+    // take 3.5 ms, 8192 take 6.4), so two pieces in flight finish in little more than the time of one -- and the
+    // first one's results are on their way to the host that much earlier.  (The wide kernels fill the register
+    // files with one piece; they are for a call that is a single piece.)
+    const bool many = pieces.size() > 1;
+    StreamSwap on(cx, many && (k & 1) ? cx.s_k2 : cx.stream);
     HIPCHK(hipStreamWaitEvent(cx.stream, sl.ev_in, 0));
     tr.lap(0);
+    if (int rc = ensure(sl.d_scr, gc * 8 + 64)) return rc;
     if (int rc = decompress_dev_locked(cx, (const uint8_t *)sl.d_in.p, (const uint64_t *)sl.d_off.p, nullptr, 0, gc, fmt,
                                        dict, (uint8_t *)sl.d_out.p, out_stride, (uint32_t *)sl.d_len.p,
-                                       (uint32_t *)sl.d_a32a.p, (int32_t *)sl.d_a32b.p))
+                                       (uint32_t *)sl.d_a32a.p, (int32_t *)sl.d_a32b.p, (uint32_t *)sl.d_scr.p,
+                                       (uint32_t *)sl.d_scr.p + gc, many ? 1 : 0))
       return rc;
     uint8_t *small = (uint8_t *)sl.pin_small.p;
     HIPCHK(hipMemcpyAsync(small, sl.d_len.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
     HIPCHK(hipMemcpyAsync(small + gc * 4, sl.d_a32a.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
     HIPCHK(hipMemcpyAsync(small + gc * 8, sl.d_a32b.p, gc * 4, hipMemcpyDeviceToHost, cx.stream));
     HIPCHK(hipEventRecord(sl.ev_done, cx.stream));
+    on.restore();
     tr.lap(1);
-    if (k > 0)
-      if (int rc = start_out(k - 1)) return rc;
-    if (k > 1)
-      if (int rc = scatter(k - 2)) return rc;
+    // (three pieces are enqueued before the first one's results are waited for: with two kernel streams a piece's
+    // input must already be on the device when the stream it will run on falls free)
+    if (k + 1 >= kInflateAhead)
+      if (int rc = start_out(k + 1 - kInflateAhead)) return rc;
+    if (k >= kInflateAhead)
+      if (int rc = scatter(k - kInflateAhead)) return rc;
   }
   const size_t np = pieces.size();
-  if (int rc = start_out(np - 1)) return rc;
-  if (np > 1)
-    if (int rc = scatter(np - 2)) return rc;
-  if (int rc = scatter(np - 1)) return rc;
+  for (size_t k = np >= kInflateAhead ? np + 1 - kInflateAhead : 0; k < np; k++)
+    if (int rc = start_out(k)) return rc;
+  for (size_t k = np > kInflateAhead ? np - kInflateAhead : 0; k < np; k++)
+    if (int rc = scatter(k)) return rc;
   drain.clean = true;
   tr.report("ldh_decompress_batch", np, pin_in, pin_out);
   return 0;
