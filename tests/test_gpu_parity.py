@@ -154,6 +154,20 @@ def test_host_batches_in_many_pieces(B, monkeypatch):
             assert g == o_decompress(raw), i
         else:
             assert g == (cases[i], 0), i
+    # zlib streams in many pieces: neighbouring pieces' kernels run side by side on two streams, each piece with
+    # trailer / Adler-32 arrays of its own (round 3); one stream with a wrong checksum, one cut inside its trailer
+    comp5 = [c for c, _ in whole5]
+    comp5[9] = comp5[9][:-1] + bytes([comp5[9][-1] ^ 1])
+    comp5[301] = comp5[301][:-2]
+    monkeypatch.setenv("LDH_PIECE_KB", "16")
+    pieces5 = B.decompress_batch(comp5, fmt=1)
+    monkeypatch.delenv("LDH_PIECE_KB")
+    assert pieces5 == B.decompress_batch(comp5, fmt=1)
+    for i, (raw, g) in enumerate(zip(comp5, pieces5)):
+        if i in (9, 301):
+            assert g == o_decompress(raw, zlib=True), i
+        else:
+            assert g == (cases[i], 0), i
 
 
 def test_synthetic_configs(B):
