@@ -200,3 +200,46 @@ def test_host_batches_on_caller_pinned_memory(LD, B):
         N.lib.ldh_host_free(p_in)
     with pytest.raises(N.LdhError):
         N.check(N.lib.ldh_host_unregister(probe.ctypes.data))    # not (or no longer) registered
+
+
+@pytest.mark.parametrize("count", [40, 1100])
+def test_inflate_of_short_distance_matches(B, count):
+    # The one-wavefront inflate stores a plain round's bytes a round later, just before the next round's loads, and
+    # relies on a CU serving its waves' memory operations in order for those loads to see them.
+    # Matches that read the bytes of the round before are what exercises that: streams of short periods (distances
+    # 1 ... 300, around the 64 bytes a round produces at most), pure, with literal noise between the repeats, and mixed
+    # with text.  40 streams take the wide kernels, 1100 one wavefront per stream; round trip of every stream on the
+    # device, a few compared with the oracle.
+    from libdeflate_amd import synth
+    rng = np.random.default_rng(1234 + count)
+    text = synth.text_streams(1, 131072)[0].tobytes()
+    streams = []
+    for i in range(count):
+        p = 1 + (i * 7) % 300
+        unit = bytes(rng.integers(0, 256, p, dtype=np.uint8))
+        n = int(rng.integers(3000, 40000))
+        kind = i % 4
+        if kind == 0:
+            s = (unit * (n // p + 1))[:n]
+        elif kind == 1:  # a literal or two between the repeats
+            parts = []
+            while sum(map(len, parts)) < n:
+                parts.append(unit * int(rng.integers(1, 6)))
+                parts.append(bytes(rng.integers(0, 256, int(rng.integers(0, 3)), dtype=np.uint8)))
+            s = b"".join(parts)[:n]
+        elif kind == 2:  # repeats of changing period
+            parts = []
+            while sum(map(len, parts)) < n:
+                q = int(rng.integers(1, 130))
+                parts.append((unit * (q // p + 2))[:q] * int(rng.integers(2, 8)))
+            s = b"".join(parts)[:n]
+        else:
+            o = int(rng.integers(0, len(text) - 2000))
+            s = ((unit * (600 // p + 1))[:600] + text[o: o + 1500]) * (n // 2100 + 1)
+            s = s[:n]
+        streams.append(s)
+    sample = [0, 1, 2, 3, count - 1]
+    for level in (5, 1):
+        got = device_round_trip(B, streams, level, sample=sample)
+        for i in sample:
+            assert got[i] == o_compress(streams[i], level=level), (level, i, len(streams[i]))
