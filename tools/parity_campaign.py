@@ -33,7 +33,8 @@ def piece(n):
     if kind == 1:
         return (noise * (n // len(noise) + 1))[:n]
     if kind == 2:
-        per = int(rng.integers(1, 40000))
+        # (half of them short: matches at distances around the 64 bytes an inflate round produces)
+        per = int(rng.integers(1, 300)) if rng.random() < 0.5 else int(rng.integers(1, 40000))
         return (noise[:per] * (n // per + 1))[:n]
     if kind == 3:
         return bytes([int(rng.integers(0, 256))]) * n
